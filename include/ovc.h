@@ -1,0 +1,197 @@
+/*
+ * ovc.h -- C ABI of the MI355X (gfx950) captioning engine ("libovc.so").
+ *
+ * The reference (hieunghia-pat/OpenViIC) has no native boundary: its hot path is eager PyTorch
+ * (ATen) dispatched from Python classes.  This header is therefore the boundary a maintainer
+ * would bind instead of those ATen call sites; every entry point names the reference lines it
+ * replaces (paths relative to the reference checkout).  All pointers are DEVICE pointers to
+ * dense row-major fp32 data unless stated otherwise; masks are one byte per element (0/1);
+ * token ids are int64.  Nothing allocates, nothing synchronises, every launch goes to the
+ * caller's hipStream_t; the return value is 0 on success or a negative OVC_E* code, and no
+ * exception crosses the boundary.  The library keeps no global mutable state except the opt-in
+ * profiling counters at the end of this header.
+ */
+#ifndef OVC_H_
+#define OVC_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* ovc_stream;              /* a hipStream_t (NULL = the null stream) */
+
+#define OVC_OK            0
+#define OVC_EINVAL       -1            /* bad argument / unsupported shape   */
+#define OVC_EWORKSPACE   -2            /* workspace too small                */
+#define OVC_ELAUNCH      -3            /* hipGetLastError() != hipSuccess    */
+
+#define OVC_MAX_LAYERS    8
+#define OVC_MAX_LEVELS    4
+#define OVC_MAX_BEAM      8
+#define OVC_MAX_SEGMENTS  8
+
+/* library / build identification ------------------------------------------------------ */
+int         ovc_abi_version(void);             /* bumps when a struct layout changes     */
+const char* ovc_build_info(void);              /* "gfx950 fp32-mfma ..."                 */
+
+/* ======================================================================================
+ * Operator level (parity-test surface; also what the host-side modules call)
+ * ==================================================================================== */
+
+/* y[M,N] = act([x | x2] W^T + bias) + residual
+ *   x  [M,K1] (row stride ldx), x2 [M,K2] or NULL (row stride ldx2), W [N,K1+K2], bias [N] or
+ *   NULL, residual [M,N] or NULL (row stride ldr), y row stride ldy.  act: 0 none, 1 relu.
+ * Replaces every nn.Linear on the path: models/modules/vision_embeddings.py:17,
+ * attentions.py:47-49,56, positionwise_feed_forward.py:24, decoders.py:121; with x2 the
+ * concatenated-input gates attentions.py:311-314 and decoders.py:61.  fp32 MFMA
+ * (v_mfma_f32_32x32x2_f32), fp32 accumulate. */
+int ovc_linear(const float* x, int ldx, const float* x2, int ldx2, int K1, int K2,
+               const float* W, const float* bias, const float* residual, int ldr,
+               float* y, int ldy, int M, int N, int act, ovc_stream stream);
+
+/* y[r,:] = LayerNorm(x[r,:] + residual[r,:]) * gamma + beta + add[r % add_rows,:]; rows with
+ * zero_rows[r] != 0 are written as 0.  residual / add / zero_rows may be NULL.
+ * Replaces nn.LayerNorm at attentions.py:309, positionwise_feed_forward.py:26, encoders.py:36
+ * (with add = positional encoding) and the masked_fill at encoders.py:20 / decoders.py:26. */
+int ovc_layer_norm(const float* x, const float* residual, const float* gamma, const float* beta,
+                   const float* add, int add_rows, const uint8_t* zero_rows, float eps,
+                   float* y, int rows, int d, ovc_stream stream);
+
+/* Scaled dot-product attention on projected heads.
+ *   q [b,nq,h*dk], k [b,nk,h*dk], v [b,nk,h*dv]  ->  out [b,nq,h*dv]
+ *   score = q.k / sqrt(dk); masked (mask != 0) scores become -inf; with geometry [b,h,nq,nk]
+ *   score = log(max(geometry, 1e-6)) + score; softmax over keys; out = P v.
+ *   mask element (b,iq,ik) is mask[b*mask_sb + iq*mask_sq + ik] (mask_sq = 0 broadcasts over
+ *   queries), NULL = no mask.  Memory slots (mem_k [m,h*dk], mem_v [m,h*dv], may be NULL):
+ *   m extra keys mem_scale_k*mem_k and values mem_scale_v*mem_v appended after the nk real
+ *   keys and never masked.  nk + m <= 128; dk, dv multiples of 4 and <= 64.
+ * Replaces attentions.py:51-55 (plain), :102-111 (geometry), :171-183 (memory). */
+int ovc_attention(const float* q, const float* k, const float* v, int b, int nq, int nk, int h,
+                  int dk, int dv, const uint8_t* mask, long mask_sb, long mask_sq,
+                  const float* geometry, const float* mem_k, const float* mem_v, int m,
+                  float mem_scale_k, float mem_scale_v, float* out, ovc_stream stream);
+
+/* mask[r] = (sum_f x[r,f] == 0)  -- models/utils.py:48-61 on feature rows. */
+int ovc_zero_row_mask(const float* x, int rows, int d, uint8_t* mask, ovc_stream stream);
+
+/* pe[b,n,c] : DETR-style 1-D sinusoid, models/modules/pos_embeddings.py:58-72.
+ * mask [b,n] or NULL; normalize != 0 divides the position by (last + 1e-6) and multiplies by
+ * scale. */
+int ovc_region_position_encoding(const uint8_t* mask, int b, int n, int d, float temperature,
+                                 int normalize, float scale, float* pe, ovc_stream stream);
+
+/* y[r,:] = table[tokens[r],:] + pos_table[positions[r],:] (pos_table/positions may be NULL).
+ * Replaces text_embeddings.py:28 and decoders.py:111-112. */
+int ovc_embed(const int64_t* tokens, const int64_t* positions, const float* table,
+              const float* pos_table, float* y, int rows, int d, ovc_stream stream);
+
+/* y = a * sigmoid(g)  -- attentions.py:313-315. */
+int ovc_sigmoid_gate(const float* a, const float* g, float* y, long n, ovc_stream stream);
+
+/* acc_out = (acc_in + sigmoid(alpha) * x) / divisor; acc_in may be NULL -- decoders.py:60-68
+ * (divisor = sqrt(levels) on the last level, 1 otherwise). */
+int ovc_gated_accumulate(const float* acc_in, const float* alpha, const float* x, float divisor,
+                         float* acc_out, long n, ovc_stream stream);
+
+/* y[r,:] = x[r,:] - logsumexp(x[r,:])  -- decoders.py:123. */
+int ovc_log_softmax(const float* x, float* y, int rows, int n, ovc_stream stream);
+
+/* w[b,h,i,j] = relu(fc_w[h,:] . emb(box_i, box_j) + fc_b[h]) with emb the 4 log-ratio
+ * features (trig = 0, d_g = 4) or their sin/cos embedding (trig != 0, d_g multiple of 8).
+ * Replaces models/utils.py:156-216 + encoders.py:93-101. */
+int ovc_box_relation_weights(const float* boxes, int b, int n, const float* fc_w,
+                             const float* fc_b, int h, int d_g, int trig, float* w,
+                             ovc_stream stream);
+
+/* One beam-search selection step for B images -- beam_search.py:45-59.
+ *   logp [B,width,V] log-probabilities; running [B,width]; alive [B,width] (1.0 / 0.0, already
+ *   multiplied by "previous word != eos"); selects the k best of the width*V candidates per
+ *   image (ties: lower flat index first, as torch's stable sort).  Frozen beams (alive = 0)
+ *   offer word 0 at their running score and -999 elsewhere; their rows of logp are rewritten
+ *   as logp*0 when masked_logp != NULL.  chosen [B,k] int64 flat indices, score [B,k]. */
+int ovc_beam_select(const float* logp, const float* running, const float* alive, int B,
+                    int width, int V, int k, int64_t* chosen, float* score, float* masked_logp,
+                    ovc_stream stream);
+
+/* ======================================================================================
+ * Engine level: the fused hot path  (models/base_transformer.py:45-53 and everything below it)
+ * ==================================================================================== */
+
+typedef struct { const float* w; const float* b; } ovc_lin;      /* nn.Linear  weight, bias  */
+typedef struct { const float* g; const float* b; } ovc_norm;     /* nn.LayerNorm weight, bias */
+
+typedef struct {
+    ovc_lin  q, k, v, o;              /* attention.fc_q / fc_k / fc_v / fc_o              */
+    ovc_norm ln;                      /* layer_norm                                        */
+    ovc_lin  aoa_i, aoa_g;            /* informative_attention / gated_attention or NULLs  */
+    const float* m_k;                 /* attention.m_k [m, h*dk] or NULL                   */
+    const float* m_v;                 /* attention.m_v [m, h*dv] or NULL                   */
+} ovc_mha;
+
+typedef struct { ovc_lin fc1, fc2; ovc_norm ln; } ovc_ffn;
+typedef struct { ovc_mha att; ovc_ffn ffn; } ovc_enc_layer;
+typedef struct {
+    ovc_mha self_att, cross_att;
+    ovc_ffn ffn;
+    ovc_lin alpha[OVC_MAX_LEVELS];    /* fc_alphas (meshed decoder) or NULLs               */
+} ovc_dec_layer;
+
+enum { OVC_ENC_PLAIN = 0, OVC_ENC_MULTILEVEL = 1, OVC_ENC_GEOMETRIC = 2 };
+enum { OVC_DEC_PLAIN = 0, OVC_DEC_MESHED = 1 };
+
+typedef struct {
+    int32_t abi;                      /* = ovc_abi_version()                               */
+    int32_t enc_kind, dec_kind;
+    int32_t d_feat, d_model, heads, d_k, d_v, d_ff;
+    int32_t n_enc, n_dec, n_levels;   /* n_levels = 1 unless dec_kind == OVC_DEC_MESHED     */
+    int32_t memory;                   /* memory slots in encoder self-attention (0 = none)  */
+    int32_t trig, d_g;                /* geometric encoder                                  */
+    int32_t vocab, max_len, pad_idx, bos_idx, eos_idx;
+    float   ln_eps;
+    ovc_lin  proj;                    /* vision_embedding.proj                              */
+    ovc_norm enc_ln;                  /* encoder.layer_norm                                 */
+    const float* fc_g_w;              /* encoder.fc_gs stacked [h, d_g] or NULL             */
+    const float* fc_g_b;              /* [h]                                                */
+    ovc_enc_layer enc[OVC_MAX_LAYERS];
+    ovc_dec_layer dec[OVC_MAX_LAYERS];
+    const float* word_emb;            /* decoder.word_emb.components.weight [V, d]          */
+    const float* pos_emb;             /* decoder.pos_emb.weight [max_len+1, d]              */
+    const float* fc;                  /* decoder.fc.weight [V, d] (no bias)                 */
+} ovc_model;
+
+/* Bytes of scratch the engine needs for batch B, N regions, beam k (return_probs adds the
+ * [B,k,T,V] buffer).  0 on invalid arguments. */
+size_t ovc_workspace_bytes(const ovc_model* m, int B, int N, int k, int return_probs);
+
+/* vision_embedding + encoder: features [B,N,d_feat] (zero rows = padding), boxes [B,N,4] or
+ * NULL -> enc_out [B,N,d] (multilevel: [B,levels,N,d]), mask_out [B,N].
+ * Replaces *.encoder_forward (models/standard_stransformer.py:33-42 etc.). */
+int ovc_encode(const ovc_model* m, const float* features, const float* boxes, int B, int N,
+               void* workspace, size_t workspace_bytes, float* enc_out, uint8_t* mask_out,
+               ovc_stream stream);
+
+/* Encoder + max_len beam-search steps + final ordering, all on the device.
+ *   ids_out  [B, out_size, max_len] int64,  logp_out [B, out_size, max_len] fp32,
+ *   all_logp_out [B, k, max_len, V] or NULL (return_probs).
+ * Replaces BaseTransformer.beam_search (models/base_transformer.py:45-53) and
+ * BeamSearch.apply/iter/select/_expand_state (models/modules/beam_search.py:19-118). */
+int ovc_beam_search(const ovc_model* m, const float* features, const float* boxes, int B, int N,
+                    int k, int out_size, void* workspace, size_t workspace_bytes,
+                    int64_t* ids_out, float* logp_out, float* all_logp_out, ovc_stream stream);
+
+/* Optional per-kernel-class device timing of the next engine calls (bench.py's roofline leg):
+ * while enabled, every GEMM launch of the engine is bracketed by hipEvents on `stream`.
+ * ovc_profile_read synchronises those events and returns launches, total milliseconds and
+ * total algorithmic FLOPs (2*M*N*K) per GEMM class (0 feature proj, 1 encoder, 2 decoder
+ * projections/FFN, 3 vocabulary). */
+#define OVC_PROFILE_CLASSES 4
+int ovc_profile_enable(int on);
+int ovc_profile_read(int cls, int64_t* launches, double* total_ms, double* total_flops);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OVC_H_ */

@@ -1,0 +1,22 @@
+"""Registry / factory surface of the engine (same names as the reference's ``builders`` package).
+
+Importing this package imports the module classes so that every registry is populated, as the
+reference does in ``builders/__init__.py:1-2``.
+"""
+from .registry import Registry
+from .attention_builder import META_ATTENTION, build_attention
+from .encoder_builder import META_ENCODER, build_encoder
+from .decoder_builder import META_DECODER, build_decoder
+from .vision_embedding_builder import META_VISION_EMBEDDING, build_vision_embedding
+from .text_embedding_builder import META_TEXT_EMBEDDING, build_text_embedding
+from .model_builder import META_ARCHITECTURE, build_model
+
+from .. import modules as _modules            # noqa: F401  (registers module classes)
+from .. import architectures as _architectures  # noqa: F401  (registers model classes)
+
+__all__ = [
+    "Registry",
+    "META_ATTENTION", "build_attention", "META_ENCODER", "build_encoder",
+    "META_DECODER", "build_decoder", "META_VISION_EMBEDDING", "build_vision_embedding",
+    "META_TEXT_EMBEDDING", "build_text_embedding", "META_ARCHITECTURE", "build_model",
+]

@@ -1,0 +1,342 @@
+// Attention kernels.
+//
+//  attention_mfma_kernel   general scaled-dot-product attention on projected heads, used by the
+//                          encoder (nq = nk = regions, optional geometry bias / memory slots), the
+//                          teacher-forced decoder and the DLCT-style cross form (nq != nk, per-query
+//                          mask).  Q.K^T and P.V run on the matrix cores (v_mfma_f32_32x32x2_f32),
+//                          the softmax row reduce on wavefront shuffles.
+//  decode_self_attention   one query row per beam against its own history through the ancestor
+//                          table (no cache re-ordering), nq = 1.
+//  decode_cross_attention  the k beams of one image share that image's projected encoder K/V,
+//                          staged once in LDS per (image, head).
+//
+// Reference call sites: models/modules/attentions.py:51-55, :102-111, :171-183.
+#include "common.h"
+
+namespace {
+
+constexpr int kQTile = 64;        // query rows per workgroup
+constexpr int kLdQK = 68;         // LDS row stride (floats) of the Q / K / V images: 64 + 4
+                                  // (68 r mod 64 = 4 r: conflict-free ds_read_b128 per lane group)
+
+struct AttnArgs {
+    const float* q; const float* k; const float* v; float* out;
+    int b, nq, nk, h, dk, dv;
+    const uint8_t* mask; long mask_sb, mask_sq;
+    const float* geometry;
+    const float* mem_k; const float* mem_v; int m; float mem_scale_k, mem_scale_v;
+    int nkp;                       // nk + m rounded up to a multiple of 32
+    int qtiles;
+};
+
+__global__ __launch_bounds__(256) void attention_mfma_kernel(AttnArgs p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int qt = blockIdx.x % p.qtiles;
+    const int hd = (blockIdx.x / p.qtiles) % p.h;
+    const int b = blockIdx.x / (p.qtiles * p.h);
+    const int q0 = qt * kQTile;
+    const int nkt = p.nk + p.m;            // real keys + memory slots
+    const int lds_s = p.nkp + 4;           // row stride of the score / probability image
+
+    float* Qs = lds;                       // [64][68]
+    float* Ks = Qs + kQTile * kLdQK;       // [nkp][68]
+    float* Vs = Ks + p.nkp * kLdQK;        // [nkp][68]
+    float* Ss = Vs + p.nkp * kLdQK;        // [64][nkp+4]
+
+    // ---- stage Q, K, V (zero-filled outside the valid region) -------------------------------
+    {
+        const int c4 = tid & 15, r0 = tid >> 4;           // 16 float4 per 64-wide row, 16 rows per pass
+        const int col = c4 * 4;
+        for (int r = r0; r < kQTile; r += 16) {
+            f32x4 val = {0.f, 0.f, 0.f, 0.f};
+            if (q0 + r < p.nq && col < p.dk)
+                val = *reinterpret_cast<const f32x4*>(p.q + ((size_t)b * p.nq + q0 + r) * (p.h * p.dk) + hd * p.dk + col);
+            *reinterpret_cast<f32x4*>(Qs + r * kLdQK + col) = val;
+        }
+        for (int r = r0; r < p.nkp; r += 16) {
+            f32x4 kv = {0.f, 0.f, 0.f, 0.f}, vv = {0.f, 0.f, 0.f, 0.f};
+            if (r < p.nk) {
+                if (col < p.dk) kv = *reinterpret_cast<const f32x4*>(p.k + ((size_t)b * p.nk + r) * (p.h * p.dk) + hd * p.dk + col);
+                if (col < p.dv) vv = *reinterpret_cast<const f32x4*>(p.v + ((size_t)b * p.nk + r) * (p.h * p.dv) + hd * p.dv + col);
+            } else if (r < nkt) {
+                const int mr = r - p.nk;
+                if (col < p.dk) kv = *reinterpret_cast<const f32x4*>(p.mem_k + (size_t)mr * (p.h * p.dk) + hd * p.dk + col) * p.mem_scale_k;
+                if (col < p.dv) vv = *reinterpret_cast<const f32x4*>(p.mem_v + (size_t)mr * (p.h * p.dv) + hd * p.dv + col) * p.mem_scale_v;
+            }
+            *reinterpret_cast<f32x4*>(Ks + r * kLdQK + col) = kv;
+            *reinterpret_cast<f32x4*>(Vs + r * kLdQK + col) = vv;
+        }
+    }
+    __syncthreads();
+
+    const int frow = lane & 31, half = lane >> 5;
+    // ---- S = Q K^T / sqrt(dk), masked, geometry-biased -> LDS ----------------------------------
+    {
+        const int ktiles = p.nkp >> 5;
+        const int ksteps = (p.dk + 7) >> 3;
+        const float inv_scale = sqrtf((float)p.dk);
+        for (int tile = wave; tile < 2 * ktiles; tile += 4) {
+            const int tq = tile / ktiles, tk = tile - tq * ktiles;
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            const float* ap = Qs + (tq * 32 + frow) * kLdQK + half * 4;
+            const float* bp = Ks + (tk * 32 + frow) * kLdQK + half * 4;
+            for (int kk = 0; kk < ksteps; ++kk) {
+                const f32x4 a = *reinterpret_cast<const f32x4*>(ap + kk * 8);
+                const f32x4 bb = *reinterpret_cast<const f32x4*>(bp + kk * 8);
+#pragma unroll
+                for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], bb[s], acc, 0, 0, 0);
+            }
+            const int kj = tk * 32 + frow;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int qi = tq * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                const int gq = q0 + qi;
+                float s = acc[r] / inv_scale;
+                if (kj >= nkt) {
+                    s = -INFINITY;
+                } else if (kj < p.nk && gq < p.nq) {
+                    if (p.mask && p.mask[(size_t)b * p.mask_sb + (size_t)gq * p.mask_sq + kj]) s = -INFINITY;
+                    if (p.geometry)
+                        s = logf(fmaxf(p.geometry[(((size_t)b * p.h + hd) * p.nq + gq) * p.nk + kj], 1e-6f)) + s;
+                }
+                Ss[qi * lds_s + kj] = s;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- row softmax: 4 lanes per row, wavefront-shuffle reduce ------------------------------------
+    {
+        const int row = tid >> 2, part = tid & 3;
+        float* srow = Ss + row * lds_s;
+        float mx = -INFINITY;
+        for (int j = part; j < p.nkp; j += 4) mx = fmaxf(mx, srow[j]);
+        mx = fmaxf(mx, __shfl_xor(mx, 1, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 2, 64));
+        float sum = 0.f;
+        for (int j = part; j < p.nkp; j += 4) {
+            const float e = expf(srow[j] - mx);
+            srow[j] = e;
+            sum += e;
+        }
+        sum += __shfl_xor(sum, 1, 64);
+        sum += __shfl_xor(sum, 2, 64);
+        for (int j = part; j < p.nkp; j += 4) srow[j] = srow[j] / sum;
+    }
+    __syncthreads();
+
+    // ---- O = P V ------------------------------------------------------------------------------------------
+    {
+        const int vtiles = (p.dv + 31) >> 5;
+        const int ksteps = p.nkp >> 3;
+        for (int tile = wave; tile < 2 * vtiles; tile += 4) {
+            const int tq = tile / vtiles, tn = tile - tq * vtiles;
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            const float* ap = Ss + (tq * 32 + frow) * lds_s + half * 4;
+            const float* bp = Vs + (half * 4) * kLdQK + tn * 32 + frow;
+            for (int kk = 0; kk < ksteps; ++kk) {
+                const f32x4 a = *reinterpret_cast<const f32x4*>(ap + kk * 8);
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], bp[(kk * 8 + s) * kLdQK], acc, 0, 0, 0);
+            }
+            const int col = tn * 32 + frow;
+            if (col < p.dv) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int gq = q0 + tq * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    if (gq < p.nq) p.out[((size_t)b * p.nq + gq) * (p.h * p.dv) + hd * p.dv + col] = acc[r];
+                }
+            }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int ovc_attention(const float* q, const float* k, const float* v, int b, int nq, int nk, int h,
+                             int dk, int dv, const uint8_t* mask, long mask_sb, long mask_sq,
+                             const float* geometry, const float* mem_k, const float* mem_v, int m,
+                             float mem_scale_k, float mem_scale_v, float* out, ovc_stream stream) {
+    if (!q || !k || !v || !out || b <= 0 || nq <= 0 || nk <= 0 || h <= 0) return OVC_EINVAL;
+    if (dk <= 0 || dv <= 0 || (dk & 3) || (dv & 3) || dk > 64 || dv > 64) return OVC_EINVAL;
+    if (m < 0 || (m > 0 && (!mem_k || !mem_v)) || nk + m > 128) return OVC_EINVAL;
+    if (!ovc_aligned16(q) || !ovc_aligned16(k) || !ovc_aligned16(v)) return OVC_EINVAL;
+    if (m > 0 && (!ovc_aligned16(mem_k) || !ovc_aligned16(mem_v))) return OVC_EINVAL;
+    AttnArgs p{};
+    p.q = q; p.k = k; p.v = v; p.out = out;
+    p.b = b; p.nq = nq; p.nk = nk; p.h = h; p.dk = dk; p.dv = dv;
+    p.mask = mask; p.mask_sb = mask_sb; p.mask_sq = mask_sq;
+    p.geometry = geometry;
+    p.mem_k = mem_k; p.mem_v = mem_v; p.m = m; p.mem_scale_k = mem_scale_k; p.mem_scale_v = mem_scale_v;
+    p.nkp = ((nk + m + 31) / 32) * 32;
+    p.qtiles = (nq + kQTile - 1) / kQTile;
+    const size_t lds_bytes = sizeof(float) * ((size_t)kQTile * kLdQK + 2 * (size_t)p.nkp * kLdQK + (size_t)kQTile * (p.nkp + 4));
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attention_mfma_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(attention_mfma_kernel, dim3(b * h * p.qtiles), dim3(256), lds_bytes, ovc_hip_stream(stream), p);
+    OVC_RETURN_IF_LAUNCH_FAILED();
+    return OVC_OK;
+}
+
+// =================================================================================================
+// Decode-time attention (engine only)
+// =================================================================================================
+
+__global__ __launch_bounds__(256) void decode_self_attention_kernel(DecodeSelfArgs p) {
+    __shared__ float sc[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = blockIdx.x;
+    const int g = lane >> 4, c = lane & 15;
+    const int t = p.t;
+    const float scale_div = sqrtf((float)p.dk);
+    for (int hd = wave; hd < p.h; hd += 4) {
+        f32x4 q4 = {0.f, 0.f, 0.f, 0.f};
+        if (4 * c < p.dk) q4 = *reinterpret_cast<const f32x4*>(p.q + (size_t)r * p.ldq + hd * p.dk + 4 * c);
+        for (int j0 = 0; j0 <= t; j0 += 4) {
+            const int j = j0 + g;
+            float part = 0.f;
+            int slot = 0;
+            if (j <= t) {
+                slot = (j == t) ? r : p.anc[(size_t)r * p.anc_ld + j];
+                if (4 * c < p.dk) {
+                    const f32x4 k4 = *reinterpret_cast<const f32x4*>(p.kcache + (size_t)j * p.pos_stride + (size_t)slot * p.ldkv + hd * p.dk + 4 * c);
+                    part = (q4[0] * k4[0] + q4[1] * k4[1]) + (q4[2] * k4[2] + q4[3] * k4[3]);
+                }
+            }
+            part += __shfl_xor(part, 1, 64);
+            part += __shfl_xor(part, 2, 64);
+            part += __shfl_xor(part, 4, 64);
+            part += __shfl_xor(part, 8, 64);
+            if (j <= t && c == 0) {
+                float s = part / scale_div;
+                if (p.padflag[(size_t)j * p.pad_ld + slot]) s = -INFINITY;
+                sc[wave][j] = s;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        {   // softmax over the t+1 scores (t < 64)
+            const float s = lane <= t ? sc[wave][lane] : -INFINITY;
+            const float mx = wave_max(s);
+            const float e = lane <= t ? expf(s - mx) : 0.f;
+            const float sum = wave_sum(e);
+            if (lane <= t) sc[wave][lane] = e / sum;
+        }
+        __builtin_amdgcn_wave_barrier();
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int j0 = 0; j0 <= t; j0 += 4) {
+            const int j = j0 + g;
+            if (j <= t && 4 * c < p.dv) {
+                const int slot = (j == t) ? r : p.anc[(size_t)r * p.anc_ld + j];
+                const f32x4 v4 = *reinterpret_cast<const f32x4*>(p.vcache + (size_t)j * p.pos_stride + (size_t)slot * p.ldkv + hd * p.dv + 4 * c);
+                acc += v4 * sc[wave][j];
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            acc[e] += __shfl_xor(acc[e], 16, 64);
+            acc[e] += __shfl_xor(acc[e], 32, 64);
+        }
+        if (g == 0 && 4 * c < p.dv) *reinterpret_cast<f32x4*>(p.out + (size_t)r * p.ldo + hd * p.dv + 4 * c) = acc;
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+int ovc_decode_self_attention(const DecodeSelfArgs& p, int rows, hipStream_t stream) {
+    if (p.t < 0 || p.t >= 64 || p.dk > 64 || p.dv > 64 || (p.dk & 3) || (p.dv & 3)) return OVC_EINVAL;
+    hipLaunchKernelGGL(decode_self_attention_kernel, dim3(rows), dim3(256), 0, stream, p);
+    OVC_RETURN_IF_LAUNCH_FAILED();
+    return OVC_OK;
+}
+
+__global__ __launch_bounds__(256) void decode_cross_attention_kernel(DecodeCrossArgs p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x, hd = blockIdx.y, lvl = blockIdx.z;
+    const int N = p.n, W = p.width;
+    float* Ks = lds;                         // [N][68]
+    float* Vs = Ks + N * kLdQK;              // [N][68]
+    float* qs = Vs + N * kLdQK;              // [W][64]
+    float* sc = qs + W * 64;                 // [W][N]
+
+    const float* kg = p.kx + (size_t)lvl * p.level_stride + (size_t)b * N * p.ldkv;
+    const float* vg = p.vx + (size_t)lvl * p.level_stride + (size_t)b * N * p.ldkv;
+    {
+        const int c4 = tid & 15, r0 = tid >> 4, col = c4 * 4;
+        for (int r = r0; r < N; r += 16) {
+            f32x4 kv = {0.f, 0.f, 0.f, 0.f}, vv = {0.f, 0.f, 0.f, 0.f};
+            if (col < p.dk) kv = *reinterpret_cast<const f32x4*>(kg + (size_t)r * p.ldkv + hd * p.dk + col);
+            if (col < p.dv) vv = *reinterpret_cast<const f32x4*>(vg + (size_t)r * p.ldkv + hd * p.dv + col);
+            *reinterpret_cast<f32x4*>(Ks + r * kLdQK + col) = kv;
+            *reinterpret_cast<f32x4*>(Vs + r * kLdQK + col) = vv;
+        }
+        for (int idx = tid; idx < W * 16; idx += 256) {
+            const int i = idx >> 4, cc = (idx & 15) * 4;
+            f32x4 qv = {0.f, 0.f, 0.f, 0.f};
+            if (cc < p.dk) qv = *reinterpret_cast<const f32x4*>(p.q + (size_t)(b * W + i) * p.ldq + hd * p.dk + cc);
+            *reinterpret_cast<f32x4*>(qs + i * 64 + cc) = qv;
+        }
+    }
+    __syncthreads();
+    const float scale_div = sqrtf((float)p.dk);
+    const int k4n = (p.dk + 3) >> 2;
+    for (int idx = tid; idx < W * N; idx += 256) {
+        const int i = idx / N, j = idx - i * N;
+        const f32x4* kr = reinterpret_cast<const f32x4*>(Ks + j * kLdQK);
+        const f32x4* qr = reinterpret_cast<const f32x4*>(qs + i * 64);
+        float acc = 0.f;
+        for (int c = 0; c < k4n; ++c) {
+            const f32x4 a = qr[c], kk = kr[c];
+            acc += (a[0] * kk[0] + a[1] * kk[1]) + (a[2] * kk[2] + a[3] * kk[3]);
+        }
+        float s = acc / scale_div;
+        if (p.encmask && p.encmask[(size_t)b * N + j]) s = -INFINITY;
+        sc[i * N + j] = s;
+    }
+    __syncthreads();
+    for (int i = wave; i < W; i += 4) {
+        float mx = -INFINITY;
+        for (int j = lane; j < N; j += 64) mx = fmaxf(mx, sc[i * N + j]);
+        mx = wave_max(mx);
+        float sum = 0.f;
+        for (int j = lane; j < N; j += 64) {
+            const float e = expf(sc[i * N + j] - mx);
+            sc[i * N + j] = e;
+            sum += e;
+        }
+        sum = wave_sum(sum);
+        for (int j = lane; j < N; j += 64) sc[i * N + j] = sc[i * N + j] / sum;
+    }
+    __syncthreads();
+    float* og = p.out + (size_t)lvl * p.out_level_stride;
+    for (int idx = tid; idx < W * p.dv; idx += 256) {
+        const int i = idx / p.dv, d = idx - i * p.dv;
+        float acc = 0.f;
+        for (int j = 0; j < N; ++j) acc += sc[i * N + j] * Vs[j * kLdQK + d];
+        og[(size_t)(b * W + i) * p.ldo + hd * p.dv + d] = acc;
+    }
+}
+
+int ovc_decode_cross_attention(const DecodeCrossArgs& p, int B, int h, int levels, hipStream_t stream) {
+    if (p.n <= 0 || p.n > 256 || p.width <= 0 || p.width > OVC_MAX_BEAM) return OVC_EINVAL;
+    if (p.dk > 64 || p.dv > 64 || (p.dk & 3) || (p.dv & 3)) return OVC_EINVAL;
+    const size_t lds_bytes = sizeof(float) * (2 * (size_t)p.n * kLdQK + (size_t)p.width * 64 + (size_t)p.width * p.n);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(decode_cross_attention_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(decode_cross_attention_kernel, dim3(B, h, levels), dim3(256), lds_bytes, stream, p);
+    OVC_RETURN_IF_LAUNCH_FAILED();
+    return OVC_OK;
+}

@@ -1,0 +1,63 @@
+"""Build ``libovc.so`` (the HIP kernels + C ABI of include/ovc.h) for gfx950 with hipcc.
+
+    python -m openviic_amd.csrc.build [--force]
+
+hipcc cross-compiles without a GPU.  The library is written next to the sources (in-tree), which
+is where ``openviic_amd.native`` loads it from; it is git-ignored.
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SOURCES = ["gemm.hip", "rowops.hip", "attention.hip", "beam.hip", "engine.hip"]
+HEADERS = ["common.h", os.path.join("..", "..", "include", "ovc.h")]
+LIBRARY = os.path.join(HERE, "libovc.so")
+ARCH = "gfx950"
+
+
+def find_hipcc() -> str:
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found (looked at $HIPCC, PATH and /opt/rocm/bin/hipcc)")
+
+
+def is_stale() -> bool:
+    if not os.path.exists(LIBRARY):
+        return True
+    built = os.path.getmtime(LIBRARY)
+    return any(os.path.getmtime(os.path.join(HERE, f)) > built for f in SOURCES + HEADERS)
+
+
+def build(force: bool = False, verbose: bool = True) -> str:
+    if not force and not is_stale():
+        return LIBRARY
+    hipcc = find_hipcc()
+    objects = []
+    procs = []
+    for src in SOURCES:
+        obj = os.path.join(HERE, src.replace(".hip", ".o"))
+        objects.append(obj)
+        cmd = [hipcc, "-O3", "-std=c++17", "--offload-arch=" + ARCH, "-fPIC", "-Wno-unused-result",
+               "-c", os.path.join(HERE, src), "-o", obj]
+        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+    failed = False
+    for src, proc in procs:
+        out, _ = proc.communicate()
+        if proc.returncode != 0:
+            failed = True
+            sys.stderr.write("hipcc failed on {}:\n{}\n".format(src, out))
+        elif verbose and out.strip():
+            sys.stderr.write(out)
+    if failed:
+        raise RuntimeError("hipcc failed; see messages above")
+    subprocess.check_call([hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIBRARY] + objects)
+    if verbose:
+        print("built", LIBRARY)
+    return LIBRARY
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)

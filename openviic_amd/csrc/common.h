@@ -1,0 +1,128 @@
+// Shared declarations of the gfx950 kernels behind include/ovc.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/ovc.h"
+
+#define OVC_WAVE 64
+
+#define OVC_RETURN_IF_LAUNCH_FAILED()                      \
+    do {                                                   \
+        if (hipGetLastError() != hipSuccess) return OVC_ELAUNCH; \
+    } while (0)
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+static inline hipStream_t ovc_hip_stream(ovc_stream s) { return reinterpret_cast<hipStream_t>(s); }
+
+static inline bool ovc_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// ---- wave-level reductions (64 lanes) ------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+    return v;
+}
+
+// ---- internal GEMM interface (gemm.hip) ---------------------------------------------------
+struct GemmSegment {
+    const float* W;      // [seg_n, K] row-major
+    const float* bias;   // [seg_n] or nullptr
+    float* C;            // [M, seg_n] with row stride ldc
+};
+
+struct GemmArgs {
+    const float* A1;     // [M, K1], row stride lda1
+    const float* A2;     // [M, K2], row stride lda2 (nullptr when K2 == 0)
+    int lda1, lda2, K1, K2;
+    int M;
+    int seg_n;           // columns per segment
+    int nseg;            // number of segments (total N = nseg * seg_n)
+    int ldc;
+    const float* R;      // residual [M, seg_n] (only with nseg == 1) or nullptr
+    int ldr;
+    int act;             // 0 none, 1 relu
+    GemmSegment seg[OVC_MAX_SEGMENTS];
+};
+
+// Launches C = act([A1|A2] W^T + bias) + R on `stream`; returns an OVC_* code.
+int ovc_gemm_launch(const GemmArgs& args, hipStream_t stream);
+
+// ---- decode-time attention (attention.hip) -------------------------------------------------
+struct DecodeSelfArgs {
+    const float* q;        // [rows, ldq]      projected queries of this step
+    int ldq;
+    const float* kcache;   // [T][slots][ldkv] projected keys, position-major
+    const float* vcache;
+    size_t pos_stride;     // floats between two positions
+    int ldkv;
+    const int32_t* anc;    // [rows][anc_ld]   slot of the ancestor that produced position j (< t)
+    int anc_ld;
+    const uint8_t* padflag;  // [T][pad_ld]    1 where the token fed at (position, slot) was <pad>
+    int pad_ld;
+    int t;                 // current position: keys 0..t (key t lives in the row's own slot)
+    int h, dk, dv;
+    float* out;            // [rows, ldo]
+    int ldo;
+};
+int ovc_decode_self_attention(const DecodeSelfArgs& p, int rows, hipStream_t stream);
+
+struct DecodeCrossArgs {
+    const float* q;        // [B*width, ldq]
+    int ldq;
+    const float* kx;       // [levels][B][N][ldkv] projected encoder keys (per decoder layer)
+    const float* vx;
+    size_t level_stride;
+    int ldkv;
+    const uint8_t* encmask;  // [B][N] or nullptr
+    int n, width;
+    int dk, dv;
+    float* out;            // [levels][B*width][ldo]
+    size_t out_level_stride;
+    int ldo;
+};
+int ovc_decode_cross_attention(const DecodeCrossArgs& p, int B, int h, int levels, hipStream_t stream);
+
+// ---- beam search (beam.hip) ------------------------------------------------------------------
+struct BeamSelectArgs {
+    const float* logits;     // [B, width, ld] raw vocabulary logits (or log-probs when is_logp)
+    int ld;
+    int is_logp;
+    const float* running;    // [B, width]
+    const float* alive;      // [B, width] or nullptr (all alive)
+    int width, V, k;
+    int64_t* chosen;         // [B, k] flat indices beam*V + word
+    float* score;            // [B, k]
+    float* masked_logp;      // [B, width, V] or nullptr
+    float* row_max_out;      // [B, width] or nullptr: log-softmax pieces for the update kernel
+    float* row_lsum_out;
+};
+int ovc_beam_select_launch(const BeamSelectArgs& p, int B, hipStream_t stream);
+
+struct BeamUpdateArgs {
+    const int64_t* chosen; const float* score;
+    const float* logits; int ld;
+    const float* row_max; const float* row_lsum;
+    const float* alive_in; float* alive_out; float* running_out;
+    const int32_t* hist_in; int32_t* hist_out;      // [B*k, T] words
+    const float* lp_in; float* lp_out;              // [B*k, T] per-token log-probs
+    const int32_t* anc_in; int32_t* anc_out;        // [B*k, T] ancestor slots
+    int32_t* next_tok;                              // [B*k]
+    int width, k, V, T, t, eos;
+};
+int ovc_beam_update_launch(const BeamUpdateArgs& p, int B, hipStream_t stream);
+
+struct BeamFinalArgs {
+    const float* running; const int32_t* hist; const float* lp;
+    int k, T, out_size;
+    int64_t* ids_out; float* logp_out; int32_t* order_out;
+};
+int ovc_beam_finalize_launch(const BeamFinalArgs& p, int B, hipStream_t stream);
+int ovc_beam_gather_all_launch(const float* all_buf, const int* order, int B, int k, int T, int V, float* all_out,
+                               hipStream_t stream);

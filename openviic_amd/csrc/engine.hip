@@ -1,0 +1,443 @@
+// The fused hot path: vision embedding + encoder + max_len beam-search steps + final ordering,
+// issued as one stream of launches with no host round trip.
+//
+// Differences from the reference's algorithm (results identical, work not):
+//   * cross-attention keys/values are projected ONCE per image and decoder layer and shared by
+//     the k beams of the image; the reference replicates the encoder output k-fold, re-gathers it
+//     every step and re-projects it every step (models/modules/beam_search.py:61,
+//     attentions.py:47-49) -- 68 % of its FLOPs;
+//   * self-attention caches PROJECTED keys/values, appended in place by the q|k|v GEMM epilogue;
+//     the reference caches un-projected inputs and re-projects the whole history each step
+//     (attentions.py:297-302);
+//   * beam re-ordering is an ancestor-slot table (int32 [rows, T]) read by the self-attention
+//     kernel; the reference physically gathers every cache (beam_search.py:19-34).
+#include <vector>
+
+#include "common.h"
+
+namespace {
+
+#define TRY(expr)                          \
+    do {                                   \
+        const int _rc = (expr);            \
+        if (_rc != OVC_OK) return _rc;     \
+    } while (0)
+
+// ---------------------------------------------------------------------------------------------
+// opt-in GEMM timing (bench.py roofline leg)
+// ---------------------------------------------------------------------------------------------
+struct ProfileRecord { hipEvent_t start, stop; double flops; };
+bool g_profile_on = false;
+std::vector<ProfileRecord> g_profile[OVC_PROFILE_CLASSES];
+
+// ---------------------------------------------------------------------------------------------
+// workspace carving
+// ---------------------------------------------------------------------------------------------
+struct Bump {
+    char* base; size_t off;
+    template <typename T> T* take(size_t count) {
+        off = (off + 255) & ~(size_t)255;
+        T* p = base ? reinterpret_cast<T*>(base + off) : nullptr;
+        off += count * sizeof(T);
+        return p;
+    }
+};
+
+struct Workspace {
+    // encoder
+    uint8_t* enc_mask; float* pe; float* xe[2]; float* eq; float* ek; float* ev; float* eatt; float* ey;
+    float* eff; float* einfo; float* egate; float* geometry; float* enc_levels;
+    float* kx; float* vx;                         // [L][levels][B][N][h*dk|h*dv]
+    // decoder
+    float* x; float* x1; float* x2; float* y; float* q; float* att; float* ff; float* info; float* gate;
+    float* enc_att; float* alpha; float* mixed;
+    float* kc; float* vc;                         // [L][T][R][h*dk|h*dv]
+    uint8_t* padflag;                             // [T][R]
+    float* logits;                                // [R][V]
+    float* running[2]; float* alive[2]; int32_t* hist[2]; float* lp[2]; int32_t* anc[2];
+    int32_t* tok; int64_t* chosen; float* score; float* row_max; float* row_lsum; int32_t* order;
+    float* all_buf;
+    size_t bytes;
+};
+
+bool model_ok(const ovc_model* m) {
+    if (!m || m->abi != ovc_abi_version()) return false;
+    if (m->n_enc < 1 || m->n_enc > OVC_MAX_LAYERS || m->n_dec < 1 || m->n_dec > OVC_MAX_LAYERS) return false;
+    if (m->n_levels < 1 || m->n_levels > OVC_MAX_LEVELS) return false;
+    if (m->d_model <= 0 || (m->d_model & 3) || m->d_model > 2048) return false;
+    if (m->d_k <= 0 || m->d_k > 64 || (m->d_k & 3) || m->d_v <= 0 || m->d_v > 64 || (m->d_v & 3)) return false;
+    if ((m->d_feat & 3) || (m->d_ff & 3) || m->heads <= 0 || m->vocab <= 1) return false;
+    if (m->max_len < 1 || m->max_len > 64) return false;
+    // fused q|k|v and cross k|v GEMMs need segment widths that are multiples of the 64-wide tile
+    if ((m->heads * m->d_k) % 64 || (m->heads * m->d_v) % 64 || (m->heads * m->d_k) != (m->heads * m->d_v)) return false;
+    if (m->dec_kind == OVC_DEC_MESHED && m->enc_kind != OVC_ENC_MULTILEVEL) return false;
+    if (m->dec_kind != OVC_DEC_MESHED && m->n_levels != 1) return false;
+    return true;
+}
+
+Workspace carve(const ovc_model* m, void* base, int B, int N, int k, int return_probs) {
+    Workspace w{};
+    Bump a{reinterpret_cast<char*>(base), 0};
+    const size_t BN = (size_t)B * N, R = (size_t)B * k, d = m->d_model, T = m->max_len;
+    const size_t hk = (size_t)m->heads * m->d_k, hv = (size_t)m->heads * m->d_v, lv = m->n_levels, L = m->n_dec;
+    w.enc_mask = a.take<uint8_t>(BN);
+    w.pe = a.take<float>((size_t)N * d);
+    w.xe[0] = a.take<float>(BN * d);
+    w.xe[1] = a.take<float>(BN * d);
+    w.eq = a.take<float>(BN * hk); w.ek = a.take<float>(BN * hk); w.ev = a.take<float>(BN * hv);
+    w.eatt = a.take<float>(BN * hv);
+    w.ey = a.take<float>(BN * d);
+    w.eff = a.take<float>(BN * m->d_ff);
+    w.einfo = a.take<float>(BN * d); w.egate = a.take<float>(BN * d);
+    w.geometry = a.take<float>(m->enc_kind == OVC_ENC_GEOMETRIC ? (size_t)B * m->heads * N * N : 0);
+    w.enc_levels = a.take<float>(lv * BN * d);
+    w.kx = a.take<float>(L * lv * BN * hk);
+    w.vx = a.take<float>(L * lv * BN * hv);
+    w.x = a.take<float>(R * d); w.x1 = a.take<float>(R * d); w.x2 = a.take<float>(R * d); w.y = a.take<float>(R * d);
+    w.q = a.take<float>(R * hk);
+    w.att = a.take<float>(lv * R * hv);
+    w.ff = a.take<float>(R * m->d_ff);
+    w.info = a.take<float>(R * d); w.gate = a.take<float>(R * d);
+    w.enc_att = a.take<float>(R * d); w.alpha = a.take<float>(R * d); w.mixed = a.take<float>(R * d);
+    w.kc = a.take<float>(L * T * R * hk);
+    w.vc = a.take<float>(L * T * R * hv);
+    w.padflag = a.take<uint8_t>(T * R);
+    w.logits = a.take<float>(R * m->vocab);
+    for (int i = 0; i < 2; ++i) {
+        w.running[i] = a.take<float>(R); w.alive[i] = a.take<float>(R);
+        w.hist[i] = a.take<int32_t>(R * T); w.lp[i] = a.take<float>(R * T); w.anc[i] = a.take<int32_t>(R * T);
+    }
+    w.tok = a.take<int32_t>(R); w.chosen = a.take<int64_t>(R); w.score = a.take<float>(R);
+    w.row_max = a.take<float>(R); w.row_lsum = a.take<float>(R); w.order = a.take<int32_t>(R);
+    w.all_buf = a.take<float>(return_probs ? T * R * (size_t)m->vocab : 0);
+    w.bytes = (a.off + 255) & ~(size_t)255;
+    return w;
+}
+
+// ---------------------------------------------------------------------------------------------
+// small engine-only kernels
+// ---------------------------------------------------------------------------------------------
+// x[r,:] = word_emb[tok[r]] + pos_emb[t+1]; padflag[r] = (tok[r] == pad).  decoders.py:95-112 in
+// stateful mode: the position is running_seq = t+1 for every row, also for <pad> rows.
+__global__ __launch_bounds__(256) void decode_embed_kernel(const int32_t* __restrict__ tok, int bos, int pad, int t,
+                                                           const float* __restrict__ table, const float* __restrict__ pos_table,
+                                                           float* __restrict__ x, uint8_t* __restrict__ padflag, int rows, int d) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int token = t == 0 ? bos : tok[row];
+    if (lane == 0) padflag[row] = token == pad ? 1 : 0;
+    const f32x4* e = reinterpret_cast<const f32x4*>(table + (size_t)token * d);
+    const f32x4* p = reinterpret_cast<const f32x4*>(pos_table + (size_t)(t + 1) * d);
+    f32x4* o = reinterpret_cast<f32x4*>(x + (size_t)row * d);
+    for (int c = lane; c < (d >> 2); c += 64) o[c] = e[c] + p[c];
+}
+
+__global__ void init_beam_state_kernel(float* running, float* alive, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { running[i] = 0.f; alive[i] = 1.f; }
+}
+
+// out[b, lvl, n, :] = levels[lvl][b][n][:]
+__global__ void interleave_levels_kernel(const float* __restrict__ levels, float* __restrict__ out, int B, int lv, size_t nd4) {
+    const size_t total = (size_t)B * lv * nd4;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t e = i % nd4, bl = i / nd4;
+        const int l = (int)(bl % lv), b = (int)(bl / lv);
+        reinterpret_cast<f32x4*>(out)[i] = reinterpret_cast<const f32x4*>(levels)[((size_t)l * B + b) * nd4 + e];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// launch helpers
+// ---------------------------------------------------------------------------------------------
+struct Engine {
+    const ovc_model* m;
+    hipStream_t stream;
+    int gemm_class;
+
+    int gemm(GemmArgs& a) {
+        if (!g_profile_on) return ovc_gemm_launch(a, stream);
+        ProfileRecord rec{};
+        if (hipEventCreate(&rec.start) != hipSuccess || hipEventCreate(&rec.stop) != hipSuccess) return OVC_ELAUNCH;
+        rec.flops = 2.0 * a.M * (double)a.seg_n * a.nseg * (a.K1 + a.K2);
+        (void)hipEventRecord(rec.start, stream);
+        const int rc = ovc_gemm_launch(a, stream);
+        (void)hipEventRecord(rec.stop, stream);
+        g_profile[gemm_class].push_back(rec);
+        return rc;
+    }
+
+    // y = act(x W^T + b) + residual
+    int linear(const float* x, int K, const ovc_lin& l, const float* residual, float* y, int M, int N, int act) {
+        GemmArgs a{};
+        a.A1 = x; a.lda1 = K; a.K1 = K; a.M = M; a.seg_n = N; a.nseg = 1; a.ldc = N;
+        a.R = residual; a.ldr = N; a.act = act;
+        a.seg[0] = GemmSegment{l.w, l.b, y};
+        return gemm(a);
+    }
+
+    // AoA gate (attentions.py:311-315): out = W_i [q; x] * sigmoid(W_g [q; x]), one two-segment GEMM.
+    int aoa(const ovc_mha& w, const float* queries, float* x, float* info, float* gate, int M) {
+        if (!w.aoa_i.w) return OVC_OK;
+        const int d = m->d_model;
+        GemmArgs a{};
+        a.A1 = queries; a.lda1 = d; a.K1 = d; a.A2 = x; a.lda2 = d; a.K2 = d;
+        a.M = M; a.seg_n = d; a.nseg = 2; a.ldc = d;
+        a.seg[0] = GemmSegment{w.aoa_i.w, w.aoa_i.b, info};
+        a.seg[1] = GemmSegment{w.aoa_g.w, w.aoa_g.b, gate};
+        if (d % 64) {   // segments must align with tiles: fall back to two launches
+            a.nseg = 1;
+            TRY(gemm(a));
+            a.seg[0] = GemmSegment{w.aoa_g.w, w.aoa_g.b, gate};
+            TRY(gemm(a));
+        } else {
+            TRY(gemm(a));
+        }
+        return ovc_sigmoid_gate(info, gate, x, (long)M * d, stream);
+    }
+
+    int ffn(const ovc_ffn& w, const float* x, float* ff, float* y, float* out, const uint8_t* zero_rows, int M) {
+        const int d = m->d_model;
+        TRY(linear(x, d, w.fc1, nullptr, ff, M, m->d_ff, 1));
+        TRY(linear(ff, m->d_ff, w.fc2, x, y, M, d, 0));
+        return ovc_layer_norm(y, nullptr, w.ln.g, w.ln.b, nullptr, 0, zero_rows, m->ln_eps, out, M, d, stream);
+    }
+};
+
+int run_encoder(Engine& e, Workspace& w, const float* features, const float* boxes, int B, int N) {
+    const ovc_model* m = e.m;
+    const int BN = B * N, d = m->d_model, hk = m->heads * m->d_k, hv = m->heads * m->d_v;
+    hipStream_t s = e.stream;
+    if (m->enc_kind == OVC_ENC_GEOMETRIC && (!boxes || !m->fc_g_w || !m->fc_g_b)) return OVC_EINVAL;
+
+    e.gemm_class = 0;
+    TRY(ovc_zero_row_mask(features, BN, m->d_feat, w.enc_mask, s));
+    TRY(e.linear(features, m->d_feat, m->proj, nullptr, w.ey, BN, d, 0));
+    e.gemm_class = 1;
+    TRY(ovc_region_position_encoding(nullptr, 1, N, d, 10000.0f, 0, 0.f, w.pe, s));
+    TRY(ovc_layer_norm(w.ey, nullptr, m->enc_ln.g, m->enc_ln.b, w.pe, N, nullptr, m->ln_eps, w.xe[0], BN, d, s));
+    if (m->enc_kind == OVC_ENC_GEOMETRIC)
+        TRY(ovc_box_relation_weights(boxes, B, N, m->fc_g_w, m->fc_g_b, m->heads, m->d_g, m->trig, w.geometry, s));
+
+    float* x = w.xe[0];
+    float* x1 = w.xe[1];
+    for (int l = 0; l < m->n_enc; ++l) {
+        const ovc_mha& at = m->enc[l].att;
+        GemmArgs a{};
+        a.A1 = x; a.lda1 = d; a.K1 = d; a.M = BN; a.seg_n = hk; a.nseg = 3; a.ldc = hk;
+        a.seg[0] = GemmSegment{at.q.w, at.q.b, w.eq};
+        a.seg[1] = GemmSegment{at.k.w, at.k.b, w.ek};
+        a.seg[2] = GemmSegment{at.v.w, at.v.b, w.ev};
+        TRY(e.gemm(a));
+        const int mem = at.m_k ? m->memory : 0;
+        TRY(ovc_attention(w.eq, w.ek, w.ev, B, N, N, m->heads, m->d_k, m->d_v, w.enc_mask, N, 0,
+                          m->enc_kind == OVC_ENC_GEOMETRIC ? w.geometry : nullptr, at.m_k, at.m_v, mem,
+                          sqrtf((float)m->d_k), sqrtf((float)(mem > 0 ? mem : 1)), w.eatt, s));
+        TRY(e.linear(w.eatt, hv, at.o, x, w.ey, BN, d, 0));
+        TRY(ovc_layer_norm(w.ey, nullptr, at.ln.g, at.ln.b, nullptr, 0, nullptr, m->ln_eps, x1, BN, d, s));
+        TRY(e.aoa(at, x, x1, w.einfo, w.egate, BN));
+        // layer output: straight into the level slot (multilevel) or the ping-pong buffer
+        float* out = m->enc_kind == OVC_ENC_MULTILEVEL ? w.enc_levels + (size_t)l * BN * d
+                                                       : (l == m->n_enc - 1 ? w.enc_levels : x);
+        TRY(e.ffn(m->enc[l].ffn, x1, w.eff, w.ey, out, w.enc_mask, BN));
+        x = out;
+    }
+    return OVC_OK;
+}
+
+// Projected cross-attention keys/values of every decoder layer: one GEMM per encoder level with
+// 2*L segments (k_0, v_0, k_1, v_1, ...) sharing the encoder output as the A operand.
+int project_cross_kv(Engine& e, Workspace& w, int B, int N) {
+    const ovc_model* m = e.m;
+    const int BN = B * N, d = m->d_model, hk = m->heads * m->d_k, lv = m->n_levels, L = m->n_dec;
+    e.gemm_class = 1;
+    for (int lvl = 0; lvl < lv; ++lvl) {
+        for (int l0 = 0; l0 < L; l0 += OVC_MAX_SEGMENTS / 2) {
+            GemmArgs a{};
+            a.A1 = w.enc_levels + (size_t)lvl * BN * d; a.lda1 = d; a.K1 = d; a.M = BN; a.seg_n = hk; a.ldc = hk;
+            int ns = 0;
+            for (int l = l0; l < L && ns + 2 <= OVC_MAX_SEGMENTS; ++l) {
+                const ovc_mha& at = m->dec[l].cross_att;
+                const size_t off = ((size_t)l * lv + lvl) * BN * hk;
+                a.seg[ns++] = GemmSegment{at.k.w, at.k.b, w.kx + off};
+                a.seg[ns++] = GemmSegment{at.v.w, at.v.b, w.vx + off};
+            }
+            a.nseg = ns;
+            TRY(e.gemm(a));
+        }
+    }
+    return OVC_OK;
+}
+
+int run_decode_step(Engine& e, Workspace& w, int B, int N, int k, int t, int return_probs) {
+    const ovc_model* m = e.m;
+    hipStream_t s = e.stream;
+    const int d = m->d_model, hk = m->heads * m->d_k, hv = m->heads * m->d_v, lv = m->n_levels, T = m->max_len;
+    const int R = B * k, width = t == 0 ? 1 : k, rows = B * width;
+    const int cur = t & 1, nxt = cur ^ 1;
+    uint8_t* padflag_t = w.padflag + (size_t)t * R;
+
+    hipLaunchKernelGGL(decode_embed_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, w.tok, m->bos_idx, m->pad_idx, t,
+                       m->word_emb, m->pos_emb, w.x, padflag_t, rows, d);
+    OVC_RETURN_IF_LAUNCH_FAILED();
+
+    e.gemm_class = 2;
+    float* x = w.x;
+    for (int l = 0; l < m->n_dec; ++l) {
+        const ovc_dec_layer& dl = m->dec[l];
+        // ---- masked self-attention over the beam's own history ------------------------------------
+        float* kc = w.kc + (size_t)l * T * R * hk;
+        float* vc = w.vc + (size_t)l * T * R * hv;
+        GemmArgs a{};
+        a.A1 = x; a.lda1 = d; a.K1 = d; a.M = rows; a.seg_n = hk; a.nseg = 3; a.ldc = hk;
+        a.seg[0] = GemmSegment{dl.self_att.q.w, dl.self_att.q.b, w.q};
+        a.seg[1] = GemmSegment{dl.self_att.k.w, dl.self_att.k.b, kc + (size_t)t * R * hk};
+        a.seg[2] = GemmSegment{dl.self_att.v.w, dl.self_att.v.b, vc + (size_t)t * R * hv};
+        TRY(e.gemm(a));
+        DecodeSelfArgs sa{};
+        sa.q = w.q; sa.ldq = hk; sa.kcache = kc; sa.vcache = vc; sa.pos_stride = (size_t)R * hk; sa.ldkv = hk;
+        sa.anc = w.anc[cur]; sa.anc_ld = T; sa.padflag = w.padflag; sa.pad_ld = R; sa.t = t;
+        sa.h = m->heads; sa.dk = m->d_k; sa.dv = m->d_v; sa.out = w.att; sa.ldo = hv;
+        TRY(ovc_decode_self_attention(sa, rows, s));
+        TRY(e.linear(w.att, hv, dl.self_att.o, x, w.y, rows, d, 0));
+        TRY(ovc_layer_norm(w.y, nullptr, dl.self_att.ln.g, dl.self_att.ln.b, nullptr, 0, nullptr, m->ln_eps, w.x1, rows, d, s));
+        TRY(e.aoa(dl.self_att, x, w.x1, w.info, w.gate, rows));
+
+        // ---- cross-attention: the image's beams share its projected encoder keys/values -----------
+        TRY(e.linear(w.x1, d, dl.cross_att.q, nullptr, w.q, rows, hk, 0));
+        DecodeCrossArgs ca{};
+        ca.q = w.q; ca.ldq = hk;
+        ca.kx = w.kx + (size_t)l * lv * B * N * hk; ca.vx = w.vx + (size_t)l * lv * B * N * hv;
+        ca.level_stride = (size_t)B * N * hk; ca.ldkv = hk; ca.encmask = w.enc_mask; ca.n = N; ca.width = width;
+        ca.dk = m->d_k; ca.dv = m->d_v; ca.out = w.att; ca.out_level_stride = (size_t)rows * hv; ca.ldo = hv;
+        TRY(ovc_decode_cross_attention(ca, B, m->heads, lv, s));
+        float* ffn_in;
+        if (m->dec_kind == OVC_DEC_MESHED) {
+            // decoders.py:51-73: one shared enc_attn per level, sigmoid-gated sum / sqrt(levels)
+            for (int lvl = 0; lvl < lv; ++lvl) {
+                TRY(e.linear(w.att + (size_t)lvl * rows * hv, hv, dl.cross_att.o, w.x1, w.y, rows, d, 0));
+                TRY(ovc_layer_norm(w.y, nullptr, dl.cross_att.ln.g, dl.cross_att.ln.b, nullptr, 0, nullptr, m->ln_eps, w.enc_att, rows, d, s));
+                TRY(e.aoa(dl.cross_att, w.x1, w.enc_att, w.info, w.gate, rows));
+                GemmArgs g{};
+                g.A1 = w.x1; g.lda1 = d; g.K1 = d; g.A2 = w.enc_att; g.lda2 = d; g.K2 = d;
+                g.M = rows; g.seg_n = d; g.nseg = 1; g.ldc = d;
+                g.seg[0] = GemmSegment{dl.alpha[lvl].w, dl.alpha[lvl].b, w.alpha};
+                TRY(e.gemm(g));
+                TRY(ovc_gated_accumulate(lvl == 0 ? nullptr : w.mixed, w.alpha, w.enc_att,
+                                         lvl == lv - 1 ? sqrtf((float)lv) : 1.0f, w.mixed, (long)rows * d, s));
+            }
+            ffn_in = w.mixed;
+        } else {
+            TRY(e.linear(w.att, hv, dl.cross_att.o, w.x1, w.y, rows, d, 0));
+            TRY(ovc_layer_norm(w.y, nullptr, dl.cross_att.ln.g, dl.cross_att.ln.b, nullptr, 0, nullptr, m->ln_eps, w.x2, rows, d, s));
+            TRY(e.aoa(dl.cross_att, w.x1, w.x2, w.info, w.gate, rows));
+            ffn_in = w.x2;
+        }
+        TRY(e.ffn(dl.ffn, ffn_in, w.ff, w.y, w.x, padflag_t, rows));
+        x = w.x;
+    }
+
+    // ---- vocabulary projection, fused log-softmax + candidate scores + top-k, bookkeeping ---------
+    e.gemm_class = 3;
+    ovc_lin fc{m->fc, nullptr};
+    TRY(e.linear(x, d, fc, nullptr, w.logits, rows, m->vocab, 0));
+    BeamSelectArgs bs{};
+    bs.logits = w.logits; bs.ld = m->vocab; bs.is_logp = 0;
+    bs.running = w.running[cur]; bs.alive = w.alive[cur]; bs.width = width; bs.V = m->vocab; bs.k = k;
+    bs.chosen = w.chosen; bs.score = w.score;
+    bs.masked_logp = return_probs ? w.all_buf + (size_t)t * R * m->vocab : nullptr;
+    bs.row_max_out = w.row_max; bs.row_lsum_out = w.row_lsum;
+    TRY(ovc_beam_select_launch(bs, B, s));
+    BeamUpdateArgs bu{};
+    bu.chosen = w.chosen; bu.score = w.score; bu.logits = w.logits; bu.ld = m->vocab;
+    bu.row_max = w.row_max; bu.row_lsum = w.row_lsum;
+    bu.alive_in = w.alive[cur]; bu.alive_out = w.alive[nxt]; bu.running_out = w.running[nxt];
+    bu.hist_in = w.hist[cur]; bu.hist_out = w.hist[nxt]; bu.lp_in = w.lp[cur]; bu.lp_out = w.lp[nxt];
+    bu.anc_in = w.anc[cur]; bu.anc_out = w.anc[nxt]; bu.next_tok = w.tok;
+    bu.width = width; bu.k = k; bu.V = m->vocab; bu.T = T; bu.t = t; bu.eos = m->eos_idx;
+    return ovc_beam_update_launch(bu, B, s);
+}
+
+}  // namespace
+
+extern "C" int ovc_abi_version(void) { return 1; }
+
+extern "C" const char* ovc_build_info(void) {
+    return "libovc gfx950 (CDNA4) fp32: v_mfma_f32_32x32x2_f32 GEMM + attention, HIP " __DATE__;
+}
+
+extern "C" size_t ovc_workspace_bytes(const ovc_model* m, int B, int N, int k, int return_probs) {
+    if (!model_ok(m) || B <= 0 || N <= 0 || N > 128 || k <= 0 || k > OVC_MAX_BEAM) return 0;
+    return carve(m, nullptr, B, N, k, return_probs).bytes;
+}
+
+extern "C" int ovc_encode(const ovc_model* m, const float* features, const float* boxes, int B, int N,
+                          void* workspace, size_t workspace_bytes, float* enc_out, uint8_t* mask_out,
+                          ovc_stream stream) {
+    if (!model_ok(m) || !features || !workspace || !enc_out || !mask_out || B <= 0 || N <= 0 || N > 128) return OVC_EINVAL;
+    if (!ovc_aligned16(features) || !ovc_aligned16(workspace) || !ovc_aligned16(enc_out)) return OVC_EINVAL;
+    Workspace w = carve(m, workspace, B, N, 1, 0);
+    if (w.bytes > workspace_bytes) return OVC_EWORKSPACE;
+    Engine e{m, ovc_hip_stream(stream), 0};
+    TRY(run_encoder(e, w, features, boxes, B, N));
+    const size_t nd = (size_t)N * m->d_model;
+    if (m->n_levels > 1) {
+        hipLaunchKernelGGL(interleave_levels_kernel, dim3(1024), dim3(256), 0, e.stream, w.enc_levels, enc_out, B,
+                           m->n_levels, nd / 4);
+        OVC_RETURN_IF_LAUNCH_FAILED();
+    } else if (hipMemcpyAsync(enc_out, w.enc_levels, sizeof(float) * B * nd, hipMemcpyDeviceToDevice, e.stream) != hipSuccess) {
+        return OVC_ELAUNCH;
+    }
+    if (hipMemcpyAsync(mask_out, w.enc_mask, (size_t)B * N, hipMemcpyDeviceToDevice, e.stream) != hipSuccess) return OVC_ELAUNCH;
+    return OVC_OK;
+}
+
+extern "C" int ovc_beam_search(const ovc_model* m, const float* features, const float* boxes, int B, int N, int k,
+                               int out_size, void* workspace, size_t workspace_bytes, int64_t* ids_out,
+                               float* logp_out, float* all_logp_out, ovc_stream stream) {
+    if (!model_ok(m) || !features || !workspace || !ids_out || !logp_out) return OVC_EINVAL;
+    if (B <= 0 || N <= 0 || N > 128 || k <= 0 || k > OVC_MAX_BEAM || out_size <= 0 || out_size > k) return OVC_EINVAL;
+    if ((long)m->vocab < k) return OVC_EINVAL;
+    if (!ovc_aligned16(features) || !ovc_aligned16(workspace)) return OVC_EINVAL;
+    const int return_probs = all_logp_out != nullptr;
+    Workspace w = carve(m, workspace, B, N, k, return_probs);
+    if (w.bytes > workspace_bytes) return OVC_EWORKSPACE;
+    Engine e{m, ovc_hip_stream(stream), 0};
+    const int R = B * k, T = m->max_len;
+
+    TRY(run_encoder(e, w, features, boxes, B, N));
+    TRY(project_cross_kv(e, w, B, N));
+    hipLaunchKernelGGL(init_beam_state_kernel, dim3((R + 255) / 256), dim3(256), 0, e.stream, w.running[0], w.alive[0], R);
+    OVC_RETURN_IF_LAUNCH_FAILED();
+    for (int t = 0; t < T; ++t) TRY(run_decode_step(e, w, B, N, k, t, return_probs));
+
+    const int fin = T & 1;
+    BeamFinalArgs bf{};
+    bf.running = w.running[fin]; bf.hist = w.hist[fin]; bf.lp = w.lp[fin];
+    bf.k = k; bf.T = T; bf.out_size = out_size; bf.ids_out = ids_out; bf.logp_out = logp_out; bf.order_out = w.order;
+    TRY(ovc_beam_finalize_launch(bf, B, e.stream));
+    if (return_probs) TRY(ovc_beam_gather_all_launch(w.all_buf, w.order, B, k, T, m->vocab, all_logp_out, e.stream));
+    return OVC_OK;
+}
+
+extern "C" int ovc_profile_enable(int on) {
+    g_profile_on = on != 0;
+    return OVC_OK;
+}
+
+extern "C" int ovc_profile_read(int cls, int64_t* launches, double* total_ms, double* total_flops) {
+    if (cls < 0 || cls >= OVC_PROFILE_CLASSES || !launches || !total_ms || !total_flops) return OVC_EINVAL;
+    *launches = 0; *total_ms = 0.0; *total_flops = 0.0;
+    for (ProfileRecord& r : g_profile[cls]) {
+        (void)hipEventSynchronize(r.stop);
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, r.start, r.stop) == hipSuccess) {
+            *launches += 1; *total_ms += ms; *total_flops += r.flops;
+        }
+        (void)hipEventDestroy(r.start);
+        (void)hipEventDestroy(r.stop);
+    }
+    g_profile[cls].clear();
+    return OVC_OK;
+}

@@ -1,0 +1,156 @@
+"""Python handle of the fused HIP engine (``ovc_encode`` / ``ovc_beam_search``).
+
+``CaptionEngine`` reads the parameter tensors of a host-side model (``architectures.py``) into the
+``ovc_model`` pointer table once, owns a cached device workspace and forwards calls on the current
+HIP stream.  Parameters are referenced, not copied: in-place updates of the tensors are seen by
+the engine; re-allocation (``.to()``) drops the engine (``BaseTransformer._apply``).
+"""
+import ctypes
+
+import torch
+
+from . import native
+from .native import check
+
+
+def _p(t):
+    if t is None:
+        return None
+    if not t.is_cuda or t.dtype != torch.float32 or not t.is_contiguous():
+        raise native.OvcError("engine parameters must be contiguous fp32 tensors on the HIP device "
+                              "(got {} {} contiguous={})".format(t.device, t.dtype, t.is_contiguous()))
+    return t.data_ptr()
+
+
+def _lin(dst, linear):
+    dst.w = _p(linear.weight.detach())
+    dst.b = _p(linear.bias.detach()) if linear.bias is not None else None
+
+
+def _norm(dst, ln):
+    dst.g, dst.b = _p(ln.weight.detach()), _p(ln.bias.detach())
+
+
+def _mha(dst, mha, keep):
+    att = mha.attention
+    _lin(dst.q, att.fc_q); _lin(dst.k, att.fc_k); _lin(dst.v, att.fc_v); _lin(dst.o, att.fc_o)
+    _norm(dst.ln, mha.layer_norm)
+    if mha.use_aoa:
+        _lin(dst.aoa_i, mha.informative_attention)
+        _lin(dst.aoa_g, mha.gated_attention)
+    if hasattr(att, "m_k"):
+        dst.m_k, dst.m_v = _p(att.m_k.detach()), _p(att.m_v.detach())
+
+
+def _ffn(dst, pwff):
+    _lin(dst.fc1, pwff.fc1); _lin(dst.fc2, pwff.fc2); _norm(dst.ln, pwff.layer_norm)
+
+
+class CaptionEngine:
+    def __init__(self, model):
+        self.lib = native.load()
+        self.model = model
+        self._keep = []          # tensors created here whose storage the pointer table references
+        self.desc = self._describe(model)
+        self._workspace = None
+        self.device = next(model.parameters()).device
+        if self.device.type != "cuda":
+            raise native.OvcError("the fused engine needs the model on a HIP device (got {}); "
+                                  "there is no CPU path".format(self.device))
+
+    # -- pointer table ------------------------------------------------------------------------
+    def _describe(self, model) -> native.Model:
+        from .modules import encoders, decoders
+        d = native.Model()
+        enc, dec = model.encoder, model.decoder
+        first = enc.layers[0].mhatt.attention
+        d.abi = native.ABI_VERSION
+        d.enc_kind = (native.ENC_MULTILEVEL if isinstance(enc, encoders.MultilevelEncoder)
+                      else native.ENC_GEOMETRIC if isinstance(enc, encoders.GeometricEncoder)
+                      else native.ENC_PLAIN)
+        d.dec_kind = native.DEC_MESHED if isinstance(dec, decoders.MeshedDecoder) else native.DEC_PLAIN
+        d.d_feat = model.vision_embedding.proj.in_features
+        d.d_model, d.heads, d.d_k, d.d_v = first.d_model, first.h, first.d_k, first.d_v
+        d.d_ff = enc.layers[0].pwff.fc1.out_features
+        d.n_enc, d.n_dec = len(enc.layers), len(dec.layers)
+        d.n_levels = dec.layers[0].nlayers if d.dec_kind == native.DEC_MESHED else 1
+        d.memory = getattr(first, "m", 0)
+        d.vocab, d.max_len = dec.fc.out_features, dec.max_len
+        d.pad_idx, d.bos_idx, d.eos_idx = dec.padding_idx, model.vocab.bos_idx, model.eos_idx
+        d.ln_eps = enc.layer_norm.eps
+        if len(enc.layers) > native.OVC_MAX_LAYERS or len(dec.layers) > native.OVC_MAX_LAYERS:
+            raise native.OvcError("at most {} layers are supported".format(native.OVC_MAX_LAYERS))
+        _lin(d.proj, model.vision_embedding.proj)
+        _norm(d.enc_ln, enc.layer_norm)
+        if d.enc_kind == native.ENC_GEOMETRIC:
+            d.trig, d.d_g = int(bool(enc.trignometric_embedding)), enc.d_g
+            w = torch.cat([fc.weight.detach() for fc in enc.fc_gs], dim=0).contiguous()
+            b = torch.cat([fc.bias.detach() for fc in enc.fc_gs], dim=0).contiguous()
+            self._keep += [w, b]
+            d.fc_g_w, d.fc_g_b = _p(w), _p(b)
+        for i, layer in enumerate(enc.layers):
+            _mha(d.enc[i].att, layer.mhatt, self._keep)
+            _ffn(d.enc[i].ffn, layer.pwff)
+        for i, layer in enumerate(dec.layers):
+            _mha(d.dec[i].self_att, layer.self_attn, self._keep)
+            _mha(d.dec[i].cross_att, layer.enc_attn, self._keep)
+            _ffn(d.dec[i].ffn, layer.pwff)
+            if d.dec_kind == native.DEC_MESHED:
+                for j, fc in enumerate(layer.fc_alphas):
+                    _lin(d.dec[i].alpha[j], fc)
+        d.word_emb = _p(dec.word_emb.components.weight.detach())
+        d.pos_emb = _p(dec.pos_emb.weight.detach())
+        d.fc = _p(dec.fc.weight.detach())
+        return d
+
+    # -- workspace ----------------------------------------------------------------------------
+    def _get_workspace(self, B, N, k, return_probs):
+        need = self.lib.ovc_workspace_bytes(ctypes.byref(self.desc), B, N, k, 1 if return_probs else 0)
+        if need == 0:
+            raise native.OvcError("unsupported engine configuration (B={}, N={}, beam={}; see ovc_workspace_bytes)"
+                                  .format(B, N, k))
+        if self._workspace is None or self._workspace.numel() < need:
+            self._workspace = None
+            self._workspace = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return self._workspace, need
+
+    @staticmethod
+    def _features(x, name):
+        if not x.is_cuda or x.dtype != torch.float32:
+            raise native.OvcError("{} must be an fp32 tensor on the HIP device (got {} {})".format(name, x.device, x.dtype))
+        return x.contiguous()
+
+    # -- calls --------------------------------------------------------------------------------
+    def encode(self, features, boxes=None):
+        features = self._features(features, "features")
+        boxes = None if boxes is None else self._features(boxes, "boxes")
+        B, N = features.shape[:2]
+        ws, need = self._get_workspace(B, N, 1, False)
+        d = self.desc
+        shape = (B, d.n_levels, N, d.d_model) if d.enc_kind == native.ENC_MULTILEVEL else (B, N, d.d_model)
+        out = torch.empty(shape, dtype=torch.float32, device=self.device)
+        mask = torch.empty(B, N, dtype=torch.uint8, device=self.device)
+        check(self.lib.ovc_encode(ctypes.byref(d), features.data_ptr(), None if boxes is None else boxes.data_ptr(),
+                                  B, N, ws.data_ptr(), need, out.data_ptr(), mask.data_ptr(),
+                                  native.stream_handle()), "ovc_encode")
+        return out, mask.view(torch.bool)[:, None, None, :]
+
+    def beam_search(self, features, boxes, batch_size, beam_size, out_size=1, return_probs=False):
+        features = self._features(features, "features")
+        boxes = None if boxes is None else self._features(boxes, "boxes")
+        B, N = features.shape[:2]
+        if B != batch_size:
+            raise native.OvcError("batch_size={} but features hold {} images".format(batch_size, B))
+        d = self.desc
+        T, V = d.max_len, d.vocab
+        ws, need = self._get_workspace(B, N, beam_size, return_probs)
+        ids = torch.empty(B, out_size, T, dtype=torch.int64, device=self.device)
+        logp = torch.empty(B, out_size, T, dtype=torch.float32, device=self.device)
+        everything = torch.empty(B, beam_size, T, V, dtype=torch.float32, device=self.device) if return_probs else None
+        check(self.lib.ovc_beam_search(ctypes.byref(d), features.data_ptr(), None if boxes is None else boxes.data_ptr(),
+                                       B, N, beam_size, out_size, ws.data_ptr(), need, ids.data_ptr(), logp.data_ptr(),
+                                       None if everything is None else everything.data_ptr(),
+                                       native.stream_handle()), "ovc_beam_search")
+        if out_size == 1:
+            ids, logp = ids.squeeze(1), logp.squeeze(1)
+        return (ids, logp, everything) if return_probs else (ids, logp)

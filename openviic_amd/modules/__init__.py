@@ -1,0 +1,8 @@
+"""Host-side mirror of the reference's ``models.modules`` (registered under the same names)."""
+from .containers import Module, ModuleList, ModuleDict
+from .attentions import (ScaledDotProductAttention, AugmentedGeometryScaledDotProductAttention,
+                         AugmentedMemoryScaledDotProductAttention, MultiHeadAttention)
+from .feed_forward import PositionWiseFeedForward
+from .embeddings import FeatureEmbedding, UsualEmbedding, SinusoidPositionalEmbedding
+from .encoders import EncoderLayer, Encoder, MultilevelEncoder, GeometricEncoder
+from .decoders import DecoderLayer, MeshedDecoderLayer, Decoder, MeshedDecoder, sinusoid_encoding_table

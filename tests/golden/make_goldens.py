@@ -1,0 +1,301 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in this directory from the reference implementation itself.
+
+Run in the build container only (the reference checkout does not exist on the GPU box):
+
+    python tests/golden/make_goldens.py [--reference /root/reference]
+
+The reference is imported, never copied: its model classes are built through its own
+``build_model`` from the ``MODEL`` node produced by ``openviic_amd.config.model_config`` (same keys
+as the reference yaml files), loaded with the deterministic weights of
+``openviic_amd.utils.synthetic`` and run on the deterministic synthetic inputs.  Only inputs that
+cannot be regenerated and the reference's outputs are stored (``*.npz``, float32/int64 arrays).
+
+Two inert stand-ins are placed in ``sys.modules`` for import-time dependencies that are absent in
+this image and unused on the hot path: ``termcolor`` (logger colours) and ``cv2`` (image loading).
+
+Fixture families:
+  G1  tiny configuration, every variant: per-module intermediates, teacher-forced log-probs,
+      beam search with ``return_probs`` and ``out_size=k``
+  G2  full-size configurations (d=512, N=50, d_feat=2048, V=10201, T=20): ids, log-probs and
+      per-decision selection gaps for greedy / beam-5 decoding
+  G3  tiny configuration with a sharpened vocabulary projection that forces <eos> and <pad>
+  G4  operator-level geometry cross-attention with nq != nk and a per-query mask (DLCT form)
+  G5  box relation embedding for both ``trignometric_embedding`` values
+"""
+import argparse
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, REPO)
+
+from openviic_amd.config import model_config                      # noqa: E402
+from openviic_amd.utils.synthetic import (SyntheticVocab, synthetic_boxes,   # noqa: E402
+                                          synthetic_features, synthetic_state_dict)
+
+TINY = dict(d_feature=32, d_model=64, heads=4, d_kv=16, d_ff=128, layers=2, memory=5)
+TINY_SHAPE = dict(B=3, N=7, V=53, T=6, k=3)
+VARIANTS = ["standard_transformer", "attention_on_attention", "meshed_memory_transformer",
+            "object_relation_transformer"]
+
+
+def import_reference(path):
+    sys.dont_write_bytecode = True
+    sys.path.insert(0, path)
+    termcolor = types.ModuleType("termcolor")
+    termcolor.colored = lambda s, *a, **k: s
+    sys.modules.setdefault("termcolor", termcolor)
+    sys.modules.setdefault("cv2", types.ModuleType("cv2"))
+    import models  # noqa: F401  (populates the reference registries)
+    from builders.model_builder import build_model
+    from utils.instance import InstanceList
+    from models.modules.beam_search import BeamSearch
+    from models.modules.attentions import MultiHeadAttention
+    from models.utils import box_relational_embedding
+    return dict(build_model=build_model, InstanceList=InstanceList, BeamSearch=BeamSearch,
+                MultiHeadAttention=MultiHeadAttention, box_relational_embedding=box_relational_embedding)
+
+
+def build_reference(ref, cfg, vocab, seed, mode, memory_dims=None):
+    cfg = cfg.clone()
+    cfg.DEVICE = "cpu"
+    model = ref["build_model"](cfg, vocab).eval()
+    weights = synthetic_state_dict(model.state_dict(), seed=seed, mode=mode, memory_dims=memory_dims)
+    missing = model.load_state_dict(weights, strict=False)
+    assert not missing.unexpected_keys, missing.unexpected_keys
+    if cfg.ARCHITECTURE == "ObjectRelationTransformer":
+        # The shipped class passes one Instance to GeometricEncoder.forward, which takes
+        # (features, boxes, padding_mask) -- a TypeError.  Wire the
+        # reference's own sub-modules by keyword, harness-side.
+        def encoder_forward(input_features, _m=model):
+            feats, mask = _m.vision_embedding(input_features.region_features)
+            return _m.encoder(features=feats, boxes=input_features.region_boxes, padding_mask=mask), mask
+        model.encoder_forward = encoder_forward
+    return model
+
+
+def make_inputs(ref, B, N, d_feature, seed, ragged, boxes):
+    items = ref["InstanceList"]()
+    items.region_features = synthetic_features(B, N, d_feature, seed=seed, ragged=ragged)
+    if boxes:
+        items.region_boxes = synthetic_boxes(B, N, seed=seed)
+    return items
+
+
+class SelectRecorder:
+    """Wraps the reference's ``BeamSearch.select`` to record decision margins."""
+
+    def __init__(self, ref):
+        self.cls = ref["BeamSearch"]
+        self.orig = self.cls.select
+        self.gap, self.inner, self.chosen, self.score = [], [], [], []
+
+    def __enter__(self):
+        rec = self
+
+        def select(this, candidate_logprob):
+            idx, val = rec.orig(this, candidate_logprob)
+            flat = candidate_logprob.view(this.b_s, -1)
+            k = this.beam_size
+            top = torch.topk(flat, min(k + 1, flat.shape[1]), dim=-1).values
+            rec.gap.append((top[:, k - 1] - top[:, k]).clone() if top.shape[1] > k
+                           else torch.full((this.b_s,), float("inf")))
+            rec.inner.append((top[:, :k - 1] - top[:, 1:k]).clone())
+            rec.chosen.append(idx.clone())
+            rec.score.append(val.clone())
+            return idx, val
+        self.cls.select = select
+        return self
+
+    def __exit__(self, *exc):
+        self.cls.select = self.orig
+
+    def arrays(self, prefix):
+        return {prefix + "gap": torch.stack(self.gap).numpy(),
+                prefix + "inner_gap": torch.stack(self.inner).numpy(),
+                prefix + "chosen": torch.stack(self.chosen).numpy(),
+                prefix + "score": torch.stack(self.score).numpy()}
+
+
+def teacher_tokens(B, T, V, seed, with_pad):
+    g = torch.Generator().manual_seed(seed + 77)
+    tok = torch.randint(4, V, (B, T), generator=g)
+    tok[:, 0] = 1
+    if with_pad:
+        tok[0, T - 2:] = 0              # trailing padding
+        if B > 1:
+            tok[1, 2] = 0               # <pad> in the middle of a sequence
+    return tok
+
+
+def hook_intermediates(model, store):
+    handles = []
+
+    def keep(name):
+        def fn(_module, _inp, out):
+            store[name] = (out[0] if isinstance(out, tuple) else out).detach().clone().numpy()
+        return fn
+    handles.append(model.vision_embedding.register_forward_hook(keep("feature_proj")))
+    for i, layer in enumerate(model.encoder.layers):
+        handles.append(layer.mhatt.register_forward_hook(keep("enc%d_mhatt" % i)))
+        handles.append(layer.register_forward_hook(keep("enc%d_out" % i)))
+    for i, layer in enumerate(model.decoder.layers):
+        handles.append(layer.self_attn.register_forward_hook(keep("dec%d_self" % i)))
+        handles.append(layer.register_forward_hook(keep("dec%d_out" % i)))
+    return handles
+
+
+def g1_tiny(ref, out_dir, variant, trig=False, tag=None):
+    s = TINY_SHAPE
+    vocab = SyntheticVocab(s["V"], s["T"])
+    cfg = model_config(variant, trignometric_embedding=trig, **TINY)
+    model = build_reference(ref, cfg, vocab, seed=11, mode="generic", memory_dims=(TINY["d_kv"], TINY["memory"]))
+    boxes = variant == "object_relation_transformer"
+    items = make_inputs(ref, s["B"], s["N"], TINY["d_feature"], seed=3, ragged=True, boxes=boxes)
+    data = {}
+    with torch.no_grad():
+        enc, mask = model.encoder_forward(items)
+        data["enc_out"], data["enc_mask"] = enc.numpy(), mask.numpy()
+        items.caption_tokens = teacher_tokens(s["B"], s["T"], s["V"], seed=5, with_pad=True)
+        data["caption_tokens"] = items.caption_tokens.numpy()
+        handles = hook_intermediates(model, data)
+        data["forward_logp"] = model(items).numpy()
+        for hnd in handles:
+            hnd.remove()
+        for k in (1, s["k"]):
+            with SelectRecorder(ref) as rec:
+                ids, logp, allp = model.beam_search(items, batch_size=s["B"], beam_size=k, out_size=k,
+                                                    return_probs=True)
+            data["beam%d_ids" % k], data["beam%d_logp" % k] = ids.numpy(), logp.numpy()
+            data["beam%d_all" % k] = allp.numpy()
+            data.update(rec.arrays("beam%d_" % k))
+        ids1, logp1 = model.beam_search(items, batch_size=s["B"], beam_size=s["k"], out_size=1)
+        data["beam_out1_ids"], data["beam_out1_logp"] = ids1.numpy(), logp1.numpy()
+    name = "g1_tiny_%s.npz" % (tag or variant)
+    np.savez_compressed(os.path.join(out_dir, name), **data)
+    print("wrote", name, {k: v.shape for k, v in data.items() if k.startswith("beam")})
+
+
+def g2_full(ref, out_dir, variant, batches=(4, 16)):
+    V, T, N, D = 10201, 20, 50, 2048
+    vocab = SyntheticVocab(V, T)
+    cfg = model_config(variant, d_feature=D)
+    model = build_reference(ref, cfg, vocab, seed=1234, mode="reference_init")
+    boxes = variant == "object_relation_transformer"
+    data = {}
+    with torch.no_grad():
+        for B, k in [(batches[0], 1), (batches[0], 5), (batches[1], 5)]:
+            items = make_inputs(ref, B, N, D, seed=0, ragged=False, boxes=boxes)
+            with SelectRecorder(ref) as rec:
+                ids, logp = model.beam_search(items, batch_size=B, beam_size=k, out_size=1)
+            p = "B%d_k%d_" % (B, k)
+            data[p + "ids"], data[p + "logp"] = ids.numpy(), logp.numpy()
+            data.update(rec.arrays(p))
+        B = batches[0]
+        items = make_inputs(ref, B, N, D, seed=0, ragged=True, boxes=boxes)
+        items.caption_tokens = teacher_tokens(B, T, V, seed=9, with_pad=True)
+        full = model(items)
+        data["fwd_tokens"] = items.caption_tokens.numpy()
+        data["fwd_max"], data["fwd_argmax"] = [x.numpy() for x in full.max(-1)]
+        data["fwd_sample"] = full[:, :, ::97].contiguous().numpy()
+        enc, _ = model.encoder_forward(items)
+        data["enc_sample"] = enc.reshape(B, -1, enc.shape[-1])[:, ::7, ::5].contiguous().numpy()
+    name = "g2_full_%s.npz" % variant
+    np.savez_compressed(os.path.join(out_dir, name), **data)
+    print("wrote", name)
+
+
+def g3_forced(ref, out_dir):
+    """<eos> and <pad> are (almost) never emitted under random weights; edit their rows.
+
+    The edited ``decoder.fc.weight`` is stored in the fixture."""
+    s = dict(TINY_SHAPE, B=6, T=8)
+    vocab = SyntheticVocab(s["V"], s["T"])
+    cfg = model_config("standard_transformer", **TINY)
+    model = build_reference(ref, cfg, vocab, seed=21, mode="generic")
+    with torch.no_grad():
+        w = model.decoder.fc.weight
+        w[vocab.eos_idx] = 1.05 * w[8]       # <eos> tracks a frequently chosen word
+        w[vocab.padding_idx] *= 2.0          # <pad> gets emitted by live beams
+    items = make_inputs(ref, s["B"], s["N"], TINY["d_feature"], seed=8, ragged=True, boxes=False)
+    data = {"decoder.fc.weight": model.decoder.fc.weight.detach().clone().numpy()}
+    with torch.no_grad():
+        with SelectRecorder(ref) as rec:
+            ids, logp, allp = model.beam_search(items, batch_size=s["B"], beam_size=s["k"], out_size=s["k"],
+                                                return_probs=True)
+    data["ids"], data["logp"], data["all"] = ids.numpy(), logp.numpy(), allp.numpy()
+    data.update(rec.arrays(""))
+    n_eos, n_pad = int((ids == 2).sum()), int((ids == 0).sum())
+    assert n_eos > 0 and n_pad > 0, (n_eos, n_pad)
+    np.savez_compressed(os.path.join(out_dir, "g3_forced_eos_pad.npz"), **data)
+    print("wrote g3_forced_eos_pad.npz  eos=%d pad=%d of %d" % (n_eos, n_pad, ids.numel()))
+
+
+def g4_dlct_operator(ref, out_dir):
+    from openviic_amd.config import ConfigNode
+    B, nq, nk, d, h = 2, 50, 99, 512, 8
+    att = ConfigNode(dict(ARCHITECTURE="AugmentedGeometryScaledDotProductAttention", HEAD=h, D_MODEL=d,
+                          D_KEY=64, D_VALUE=64, D_FF=2048, USE_AOA=False, CAN_BE_STATEFUL=False, DROPOUT=0.1))
+    mha = ref["MultiHeadAttention"](att).eval()
+    sd = synthetic_state_dict({"x." + k: v for k, v in mha.state_dict().items()}, seed=31, mode="generic")
+    mha.load_state_dict({k[2:]: v for k, v in sd.items()})
+    g = torch.Generator().manual_seed(41)
+    q = torch.randn(B, nq, d, generator=g)
+    kv = torch.randn(B, nk, d, generator=g)
+    geo = torch.rand(B, h, nq, nk, generator=g) * 2.0 - 0.5          # negatives exercise clamp(1e-6)
+    mask = torch.rand(B, 1, nq, nk, generator=g) < 0.3
+    mask[:, :, :, 0] = False                                          # no fully masked row
+    with torch.no_grad():
+        out = mha(queries=q, keys=kv, values=kv, padding_mask=None, attention_mask=mask,
+                  relative_geometry_weights=geo)
+    np.savez_compressed(os.path.join(out_dir, "g4_dlct_cross_attention.npz"),
+                        queries=q.numpy(), keys=kv.numpy(), geometry=geo.numpy(), mask=mask.numpy(),
+                        out=out.numpy())
+    print("wrote g4_dlct_cross_attention.npz")
+
+
+def g5_box_relation(ref, out_dir):
+    boxes = synthetic_boxes(2, 9, seed=5)
+    boxes[1, 3] = boxes[1, 2]                                         # identical boxes -> clamp(1e-3) branch
+    data = {"boxes": boxes.numpy()}
+    for trig in (False, True):
+        emb = ref["box_relational_embedding"](boxes, dim_g=16 if trig else 4, trignometric_embedding=trig)
+        data["trig" if trig else "plain"] = emb.numpy()
+    np.savez_compressed(os.path.join(out_dir, "g5_box_relation.npz"), **data)
+    print("wrote g5_box_relation.npz")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--reference", default="/root/reference")
+    ap.add_argument("--only", default="")
+    args = ap.parse_args()
+    torch.set_num_threads(8)
+    ref = import_reference(args.reference)
+    want = set(args.only.split(",")) if args.only else None
+
+    def on(tag):
+        return want is None or tag in want
+    if on("g1"):
+        for v in VARIANTS:
+            g1_tiny(ref, HERE, v)
+        g1_tiny(ref, HERE, "object_relation_transformer", trig=True, tag="object_relation_transformer_trig")
+    if on("g3"):
+        g3_forced(ref, HERE)
+    if on("g4"):
+        g4_dlct_operator(ref, HERE)
+    if on("g5"):
+        g5_box_relation(ref, HERE)
+    if on("g2"):
+        for v in VARIANTS:
+            g2_full(ref, HERE, v)
+
+
+if __name__ == "__main__":
+    main()
