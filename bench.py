@@ -1,0 +1,219 @@
+#!/usr/bin/env python3
+"""Headline benchmark: captions/s of beam-5 decoding on synthetic region features.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config standard_transformer]
+                    [--batch 256] [--beam 5] [--no-cpu-baseline]
+
+One "step" is one pass of the hot path over one batch: ``[B=256, 50, 2048]`` fp32 region features
+already resident in HBM -> encoder -> 20 beam-search steps (beam 5, V=10201) -> token ids
+``[B, 20]``, plus (N > 1) the one RCCL all-gather of the ids.  Images shard data-parallel: every
+rank decodes its own B images (weak scaling), no data-path collective.  Rank 0 prints ONE JSON
+line; ``value`` is whole-job captions/s (all ranks' images / max-over-ranks time).
+
+``roofline`` covers the dominant kernel, the fp32 MFMA GEMM (every projection / FFN / vocabulary
+product): algorithmic FLOPs 2*M*N*K per launch over its hipEvent-bracketed duration on the launch
+stream, measured in an extra instrumented pass after the timed region.  ``cpu_baseline`` times the
+CPU oracle (which reproduces the reference's operation sequence) on a bounded sample.
+"""
+import argparse
+import json
+import os
+import statistics
+import sys
+import time
+
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+from openviic_amd.builders import build_model                                   # noqa: E402
+from openviic_amd.config import model_config                                    # noqa: E402
+from openviic_amd.instance import InstanceList                                  # noqa: E402
+from openviic_amd.utils.synthetic import (SyntheticVocab, synthetic_boxes, synthetic_features,   # noqa: E402
+                                          synthetic_state_dict)
+
+V, T, N_REGIONS, D_FEAT = 10201, 20, 50, 2048
+PEAK_F32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+GFLOP_PER_CAPTION = {"standard_transformer": 4.374, "standard_transformer_using_region": 4.374,
+                     "attention_on_attention": None, "object_relation_transformer": 4.374,
+                     "meshed_memory_transformer": 6.270}     # SURVEY.md section 8d (minimal algorithm)
+GEMM_CLASSES = ["feature_proj", "encoder", "decoder_proj_ffn", "vocab"]
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="standard_transformer")
+    ap.add_argument("--batch", type=int, default=256, help="images per GPU per step")
+    ap.add_argument("--beam", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=48, help="images in the CPU-oracle sample")
+    return ap.parse_args()
+
+
+def usable_cores():
+    """Cores this process may really use: affinity mask and cgroup CPU quota, not the host total
+    (a GPU box hands a 1-GPU job a share of the host, and oversubscribing it stalls OpenMP)."""
+    cores = os.cpu_count() or 1
+    try:
+        cores = min(cores, len(os.sched_getaffinity(0)))
+    except AttributeError:
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as f:
+                fields = f.read().split()
+            if path.endswith("cpu.max"):
+                if fields[0] != "max":
+                    cores = min(cores, max(1, int(int(fields[0]) / int(fields[1]))))
+            else:
+                quota = int(fields[0])
+                with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                    period = int(f.read())
+                if quota > 0:
+                    cores = min(cores, max(1, quota // period))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return max(1, min(cores, 32))
+
+
+def cpu_baseline(cfg, sd, variant, beam, sample):
+    """Oracle (kind "port": reference op sequence restated on PyTorch-CPU) on the host cores."""
+    from oracle.captioner import OracleCaptioner        # checker / baseline only, never the product path
+    cores = usable_cores()
+    torch.set_num_threads(cores)
+    print("[bench] cpu baseline: %d images on %d threads (host reports %d cpus)" % (sample, cores, os.cpu_count() or 0),
+          file=sys.stderr, flush=True)
+    oracle = OracleCaptioner(cfg, sd, V, T)
+    feats = synthetic_features(sample, N_REGIONS, D_FEAT, seed=0)
+    boxes = synthetic_boxes(sample, N_REGIONS, seed=0) if variant == "object_relation_transformer" else None
+    oracle.beam_search(feats[:4], beam, boxes=None if boxes is None else boxes[:4])       # warm-up
+    times = []
+    for _ in range(2):
+        t0 = time.perf_counter()
+        oracle.beam_search(feats, beam, boxes=boxes)
+        times.append(time.perf_counter() - t0)
+        print("[bench] cpu baseline repeat: %.2f s" % times[-1], file=sys.stderr, flush=True)
+    return {"value": round(sample / statistics.median(times), 3), "unit": "captions/s", "cores": cores,
+            "kind": "port",
+            "sample": "%d images, beam %d, same weights/inputs, 1 warm-up + 2 timed repeats (median), "
+                      "torch %s CPU fp32, %d threads" % (sample, beam, torch.__version__, cores)}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    distributed = world > 1
+    if args.gpus != world and not (args.gpus == 1 and world == 1):
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device; the engine has no CPU path")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if distributed:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=device)
+
+    variant, B, k = args.config, args.batch, args.beam
+    vocab = SyntheticVocab(V, T)
+    cfg = model_config(variant, d_feature=D_FEAT, device=str(device))
+    model = build_model(cfg, vocab).eval()
+    sd = synthetic_state_dict(model.state_dict(), seed=1234, mode="reference_init")
+    model.load_state_dict(sd, strict=False)
+
+    # every rank draws the same global batch and takes its contiguous shard
+    feats = synthetic_features(B * world, N_REGIONS, D_FEAT, seed=0)[rank * B:(rank + 1) * B]
+    items = InstanceList()
+    items.region_features = feats.to(device)
+    if variant == "object_relation_transformer":
+        items.region_boxes = synthetic_boxes(B * world, N_REGIONS, seed=0)[rank * B:(rank + 1) * B].to(device)
+
+    gathered = [torch.empty(B, T, dtype=torch.int64, device=device) for _ in range(world)] if distributed else None
+
+    def step():
+        ids, _ = model.beam_search(items, batch_size=B, beam_size=k, out_size=1)
+        if distributed:
+            dist.all_gather(gathered, ids)          # the path's one exchange: token ids for evaluation
+        return ids
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            step()
+        torch.cuda.synchronize()
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+    if distributed:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    result = None
+    if rank == 0:
+        from openviic_amd import native
+        import ctypes
+        lib = native.load()
+        # ---- instrumented pass: hipEvents around every GEMM launch, on the launch stream ----------
+        lib.ovc_profile_enable(1)
+        with torch.no_grad():
+            model.beam_search(items, batch_size=B, beam_size=k, out_size=1)
+        torch.cuda.synchronize()
+        lib.ovc_profile_enable(0)
+        per_class, tot_n, tot_ms, tot_fl = {}, 0, 0.0, 0.0
+        for c, name in enumerate(GEMM_CLASSES):
+            n, ms, fl = ctypes.c_int64(), ctypes.c_double(), ctypes.c_double()
+            lib.ovc_profile_read(c, ctypes.byref(n), ctypes.byref(ms), ctypes.byref(fl))
+            if n.value:
+                per_class[name] = {"launches": n.value, "ms": round(ms.value, 4),
+                                   "tflops": round(fl.value / ms.value / 1e9, 2)}
+            tot_n += n.value; tot_ms += ms.value; tot_fl += fl.value
+        achieved = tot_fl / tot_ms / 1e9 if tot_ms else 0.0
+        captions_per_s = B * world * args.steps / elapsed
+        print("[bench] gpu: %.1f captions/s, %.2f ms/step; gemm %.2f TFLOP/s over %d launches"
+              % (captions_per_s, 1e3 * elapsed / args.steps, achieved, tot_n), file=sys.stderr, flush=True)
+        gflop = GFLOP_PER_CAPTION.get(variant)
+        roofline = {"bound": "mfma", "kernel": "gemm_f32_mfma (v_mfma_f32_32x32x2_f32)",
+                    "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                    "launches_per_step": tot_n, "avg_launch_us": round(1e3 * tot_ms / max(tot_n, 1), 2),
+                    "gemm_ms_per_step": round(tot_ms, 3), "per_class": per_class}
+        if gflop:
+            e2e = captions_per_s / world * gflop / 1e3
+            roofline["end_to_end"] = {"gflop_per_caption": gflop, "achieved": round(e2e, 2),
+                                      "frac": round(e2e / PEAK_F32_MFMA_TFLOPS, 4)}
+        result = {
+            "metric": "captions/sec (whole node) at beam=%d, %d regions x d%d" % (k, N_REGIONS, D_FEAT),
+            "value": round(captions_per_s, 2), "unit": "captions/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "%s beam=%d, B=%d per GPU, %dx%d synthetic regions, V=%d, max_len=%d, "
+                                   "random-init weights" % (variant, k, B, N_REGIONS, D_FEAT, V, T),
+                       "global_batch": B * world, "parallelism": "dp%d" % world},
+            "roofline": roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(cfg, sd, variant, k, args.cpu_sample)
+        print(json.dumps(result), flush=True)
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

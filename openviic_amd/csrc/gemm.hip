@@ -77,29 +77,51 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma(GemmArgs p, int tiles_m, in
 
     f32x4 stage_a[Cfg::kLoadA], stage_b[Cfg::kLoadB];
 
+    // Branch-free tile loads: a runtime "load or zero" choice per element makes hipcc branch around
+    // every load and wait vmcnt(0) in between (serialised L2 round trips).  Instead the address is
+    // clamped in-bounds and the load is unconditional; a K tail (never present in the model shapes) is
+    // zeroed when the registers are written to LDS.  Which of A1 / A2 a K tile comes from is
+    // wave-uniform because K1 is a multiple of BK whenever K2 > 0.
+    const bool k_tail = (K % BK) != 0 || (p.K1 % BK) != 0;   // uniform; false for every real shape
+    bool a_ok = true, w_ok = true;
     auto load_tile = [&](int kt) {
         const int kq = tid & 7;
-        const int k = kt * BK + kq * 4;
+        const int k0 = kt * BK;
+        const bool second = k0 >= p.K1;                       // uniform
+        const float* __restrict__ Ab = second ? p.A2 : p.A1;
+        const int lda = second ? p.lda2 : p.lda1;
+        const int klim = second ? p.K2 : p.K1;
+        const int ka = (second ? k0 - p.K1 : k0) + kq * 4;
+        const int kw = k0 + kq * 4;
+        a_ok = ka < klim;
+        w_ok = kw < K;
+        const int kac = min(ka, klim - 4);
+        const int kwc = min(kw, K - 4);
 #pragma unroll
         for (int i = 0; i < Cfg::kLoadA; ++i) {
             const int row = (tid >> 3) + i * 32;
             const int gm = min(m0 + row, p.M - 1);
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (k < p.K1) v = *reinterpret_cast<const f32x4*>(p.A1 + (size_t)gm * p.lda1 + k);
-            else if (k < K) v = *reinterpret_cast<const f32x4*>(p.A2 + (size_t)gm * p.lda2 + (k - p.K1));
-            stage_a[i] = v;
+            stage_a[i] = *reinterpret_cast<const f32x4*>(Ab + (size_t)gm * lda + kac);
         }
 #pragma unroll
         for (int i = 0; i < Cfg::kLoadB; ++i) {
             const int row = (tid >> 3) + i * 32;
             const int gn = min(n0 + row, p.seg_n - 1);
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (k < K) v = *reinterpret_cast<const f32x4*>(W + (size_t)gn * K + k);
-            stage_b[i] = v;
+            stage_b[i] = *reinterpret_cast<const f32x4*>(W + (size_t)gn * K + kwc);
         }
     };
+    // The loaded registers are first touched here, after the MFMA block of the previous tile, so the
+    // global-load latency hides under the matrix work (issue early / write late).
     auto store_tile = [&](int buf) {
         const int kq = tid & 7;
+        if (k_tail) {
+#pragma unroll
+            for (int i = 0; i < Cfg::kLoadA; ++i)
+                if (!a_ok) stage_a[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < Cfg::kLoadB; ++i)
+                if (!w_ok) stage_b[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
 #pragma unroll
         for (int i = 0; i < Cfg::kLoadA; ++i) {
             const int row = (tid >> 3) + i * 32;
@@ -159,22 +181,40 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma(GemmArgs p, int tiles_m, in
     const float* __restrict__ bias = p.seg[seg].bias;
     float* __restrict__ C = p.seg[seg].C;
     const int half = lane >> 5;
+    const bool has_res = p.R != nullptr;                          // uniform
+    const bool interior = m0 + BM <= p.M && n0 + BN <= p.seg_n;   // uniform: no bounds checks needed
 #pragma unroll
     for (int j = 0; j < Cfg::TN; ++j) {
         const int n = n0 + wn * Cfg::kWaveN + j * 32 + (lane & 31);
-        if (n >= p.seg_n) continue;
-        const float bv = bias ? bias[n] : 0.f;
+        const int nc = min(n, p.seg_n - 1);
+        const float bv = bias ? bias[nc] : 0.f;
 #pragma unroll
         for (int i = 0; i < Cfg::TM; ++i) {
             const int mbase = m0 + wm * Cfg::kWaveM + i * 32 + 4 * half;
+            float out[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int m = mbase + (r & 3) + 8 * (r >> 2);
-                if (m < p.M) {
-                    float v = acc[i][j][r] + bv;
-                    if (p.act == 1) v = fmaxf(v, 0.f);
-                    if (p.R) v += p.R[(size_t)m * p.ldr + n];
-                    C[(size_t)m * p.ldc + n] = v;
+                float v = acc[i][j][r] + bv;
+                out[r] = p.act == 1 ? fmaxf(v, 0.f) : v;
+            }
+            if (has_res) {
+                float res[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int mc = min(mbase + (r & 3) + 8 * (r >> 2), p.M - 1);
+                    res[r] = p.R[(size_t)mc * p.ldr + nc];         // unconditional, clamped in-bounds
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) out[r] += res[r];
+            }
+            if (interior) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) C[(size_t)(mbase + (r & 3) + 8 * (r >> 2)) * p.ldc + n] = out[r];
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = mbase + (r & 3) + 8 * (r >> 2);
+                    if (m < p.M && n < p.seg_n) C[(size_t)m * p.ldc + n] = out[r];
                 }
             }
         }
@@ -218,6 +258,7 @@ int ovc_gemm_launch(const GemmArgs& a, hipStream_t stream) {
     if ((a.K1 & 3) || (a.K2 & 3) || (a.lda1 & 3) || (a.K2 && (a.lda2 & 3))) return OVC_EINVAL;
     if (!ovc_aligned16(a.A1) || (a.K2 && !ovc_aligned16(a.A2))) return OVC_EINVAL;
     if (a.R && a.nseg != 1) return OVC_EINVAL;
+    if (a.K2 > 0 && (a.K1 % BK)) return OVC_EINVAL;      // the A1|A2 seam must fall on a K-tile boundary
     for (int s = 0; s < a.nseg; ++s)
         if (!a.seg[s].W || !a.seg[s].C || !ovc_aligned16(a.seg[s].W)) return OVC_EINVAL;
 

@@ -81,15 +81,26 @@ def batch(feats, boxes=None, tokens=None, device="cuda", field="region_features"
     return items
 
 
+def decided_images(gaps, inner_gaps, tol):
+    """Images whose every beam-boundary decision (k-th vs (k+1)-th candidate, each step) and whose
+    final best-vs-second ordering had a margin above ``tol`` in the reference run.
+
+    Margins *inside* the selected set only permute beam slots and do not change the result unless
+    a later decision is itself a tie, so they are not part of the criterion.  Exact ties (margin
+    0) are unspecified in the reference: ``torch.sort`` is not stable there.
+    """
+    margin = np.asarray(gaps).min(axis=0)                                  # (B,) over steps
+    inner = np.asarray(inner_gaps)
+    if inner.size:
+        margin = np.minimum(margin, inner[-1, :, 0])                       # final ordering, out_size = 1
+    return margin > tol
+
+
 def assert_ids_match_where_decided(ids, ref_ids, gaps, inner_gaps, tol, what=""):
-    """Token ids must be identical for every image whose selection decisions all had a margin
-    above ``tol`` in the reference; returns the fraction of images that were compared."""
+    """Token ids must be identical for every decided image; returns the boolean decided mask."""
     ids, ref_ids = np.asarray(ids), np.asarray(ref_ids)
-    margin = np.asarray(gaps).min(axis=0)                     # (B,) over steps
-    if inner_gaps is not None and np.asarray(inner_gaps).size:
-        margin = np.minimum(margin, np.asarray(inner_gaps).min(axis=(0, 2)))
-    decided = margin > tol
+    decided = decided_images(gaps, inner_gaps, tol)
     assert decided.any(), "no image has all margins above {}".format(tol)
     bad = [b for b in np.nonzero(decided)[0] if not np.array_equal(ids[b], ref_ids[b])]
     assert not bad, "{}: ids differ for decided images {}".format(what, bad)
-    return decided.mean()
+    return decided
