@@ -50,6 +50,9 @@ def parse():
     ap.add_argument("--config", default="standard_transformer")
     ap.add_argument("--batch", type=int, default=256, help="images per GPU per step")
     ap.add_argument("--beam", type=int, default=5)
+    ap.add_argument("--streams", type=int, default=2,
+                    help="HIP streams that consecutive (independent) batches alternate on; decode steps are "
+                         "small launches, so two batches in flight fill the chip better than one")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=48, help="images in the CPU-oracle sample")
     return ap.parse_args()
@@ -137,10 +140,18 @@ def main():
 
     gathered = [torch.empty(B, T, dtype=torch.int64, device=device) for _ in range(world)] if distributed else None
 
+    streams = [torch.cuda.Stream(device=device) for _ in range(max(1, args.streams))]
+    issued = [0]
+
     def step():
-        ids, _ = model.beam_search(items, batch_size=B, beam_size=k, out_size=1)
-        if distributed:
-            dist.all_gather(gathered, ids)          # the path's one exchange: token ids for evaluation
+        # consecutive batches are independent: alternate them over the streams (each stream has its own
+        # engine workspace), so a batch's small decode launches overlap the other batch's
+        stream = streams[issued[0] % len(streams)]
+        issued[0] += 1
+        with torch.cuda.stream(stream):
+            ids, _ = model.beam_search(items, batch_size=B, beam_size=k, out_size=1)
+            if distributed:
+                dist.all_gather(gathered, ids)      # the path's one exchange: token ids for evaluation
         return ids
 
     with torch.no_grad():
@@ -204,7 +215,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": "%s beam=%d, B=%d per GPU, %dx%d synthetic regions, V=%d, max_len=%d, "
                                    "random-init weights" % (variant, k, B, N_REGIONS, D_FEAT, V, T),
-                       "global_batch": B * world, "parallelism": "dp%d" % world},
+                       "global_batch": B * world, "parallelism": "dp%d" % world, "streams": len(streams)},
             "roofline": roofline,
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -191,6 +191,10 @@ int ovc_beam_search(const ovc_model* m, const float* features, const float* boxe
 int ovc_profile_enable(int on);
 int ovc_profile_read(int cls, int64_t* launches, double* total_ms, double* total_flops);
 
+/* Tuning hook (tools/gemm_bench.py): force GEMM tiling 0..6 (see csrc/gemm.hip) for every
+ * following ovc_linear / engine GEMM in this process; -1 restores the automatic choice. */
+int ovc_debug_force_gemm_tiling(int tiling);
+
 #ifdef __cplusplus
 }
 #endif

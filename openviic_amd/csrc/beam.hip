@@ -35,106 +35,154 @@ __device__ __forceinline__ Cand wave_best(Cand c) {
     return c;
 }
 
+// Insert (cv, ci) into a descending sorted list of length k (k <= kMaxK) held in registers.
+__device__ __forceinline__ void list_insert(float (&lv)[kMaxK], int (&li)[kMaxK], int k, float cv, int ci) {
+#pragma unroll
+    for (int s = 0; s < kMaxK; ++s) {
+        if (s < k && better(cv, ci, lv[s], li[s])) {
+            const float tv = lv[s]; const int ti = li[s];
+            lv[s] = cv; li[s] = ci; cv = tv; ci = ti;
+        }
+    }
+}
+
+// k rounds of wave-wide argmax over the heads of the lanes' sorted lists: after the call lane r (r < k)
+// of the wave holds the wave's r-th best candidate.
+__device__ __forceinline__ Cand wave_topk(const float (&lv)[kMaxK], const int (&li)[kMaxK], int k, int lane) {
+    int head = 0;
+    Cand mine; mine.v = -INFINITY; mine.idx = 0x7fffffff;
+    for (int round = 0; round < k; ++round) {
+        Cand c; c.v = -INFINITY; c.idx = 0x7fffffff;
+#pragma unroll
+        for (int s = 0; s < kMaxK; ++s)
+            if (s == head) { c.v = lv[s]; c.idx = li[s]; }
+        const Cand w = wave_best(c);
+        if (c.idx == w.idx && w.idx != 0x7fffffff) ++head;     // candidate indices are unique
+        if (lane == round) mine = w;
+    }
+    return mine;
+}
+
+// One workgroup (1024 threads = 16 waves) per image.  The image's width*V logits are read from
+// memory exactly once into registers (all loads in flight together: the kernel is latency-bound, not
+// bandwidth-bound), the log-sum-exp of every live row and the candidate scores are computed from those
+// registers, each wave reduces its lanes' lists to the wave's k best with shuffles, and after a single
+// barrier wave 0 merges the 16*k survivors.
+template <int kPerThread, int kRows>
 __global__ __launch_bounds__(kSelThreads) void beam_select_kernel(BeamSelectArgs p) {
-    __shared__ float red[16];
-    __shared__ float row_max[kMaxK], row_lsum[kMaxK];
-    __shared__ float cand_v[16];
-    __shared__ int cand_i[16];
-    __shared__ int winner_idx;
+    __shared__ float red_max[16][kMaxK], red_sum[16][kMaxK];
+    __shared__ float fin_v[16 * kMaxK];
+    __shared__ int fin_i[16 * kMaxK];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.x;
     const int W = p.width, V = p.V, k = p.k;
     const float* x = p.logits + (size_t)b * W * p.ld;
 
-    // ---- log-sum-exp of every live row (skipped when the input already holds log-probabilities)
-    for (int i = 0; i < W; ++i) {
-        if (p.is_logp) { if (tid == 0) { row_max[i] = 0.f; row_lsum[i] = 0.f; } continue; }
-        const float* xr = x + (size_t)i * p.ld;
-        float mx = -INFINITY;
-        for (int c = tid; c < V; c += kSelThreads) mx = fmaxf(mx, xr[c]);
-        mx = wave_max(mx);
-        if (lane == 0) red[wave] = mx;
-        __syncthreads();
-        mx = red[0];
+    float xv[kRows][kPerThread];
 #pragma unroll
-        for (int w = 1; w < 16; ++w) mx = fmaxf(mx, red[w]);
-        __syncthreads();
-        float s = 0.f;
-        for (int c = tid; c < V; c += kSelThreads) s += expf(xr[c] - mx);
-        s = wave_sum(s);
-        if (lane == 0) red[wave] = s;
-        __syncthreads();
-        if (tid == 0) {
-            float tot = 0.f;
-            for (int w = 0; w < 16; ++w) tot += red[w];
-            row_max[i] = mx;
-            row_lsum[i] = logf(tot);
+    for (int i = 0; i < kRows; ++i) {
+        if (i < W) {
+#pragma unroll
+            for (int j = 0; j < kPerThread; ++j) {
+                const int c = tid + j * kSelThreads;
+                xv[i][j] = c < V ? x[(size_t)i * p.ld + c] : -INFINITY;
+            }
+        }
+    }
+
+    // ---- log-sum-exp per row: (x - max) - log(sum exp(x - max)), as ATen's log_softmax -----------------
+    float mx[kRows], ls[kRows];
+    if (!p.is_logp) {
+#pragma unroll
+        for (int i = 0; i < kRows; ++i) {
+            if (i < W) {
+                float m = -INFINITY;
+#pragma unroll
+                for (int j = 0; j < kPerThread; ++j) m = fmaxf(m, xv[i][j]);
+                m = wave_max(m);
+                if (lane == 0) red_max[wave][i] = m;
+            }
         }
         __syncthreads();
+#pragma unroll
+        for (int i = 0; i < kRows; ++i) {
+            if (i < W) {
+                float m = red_max[0][i];
+#pragma unroll
+                for (int w = 1; w < 16; ++w) m = fmaxf(m, red_max[w][i]);
+                mx[i] = m;
+                float sum = 0.f;
+#pragma unroll
+                for (int j = 0; j < kPerThread; ++j) sum += expf(xv[i][j] - m);     // exp(-inf) = 0 for the tail
+                sum = wave_sum(sum);
+                if (lane == 0) red_sum[wave][i] = sum;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < kRows; ++i) {
+            if (i < W) {
+                float tot = 0.f;
+#pragma unroll
+                for (int w = 0; w < 16; ++w) tot += red_sum[w][i];
+                ls[i] = logf(tot);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < kRows; ++i) { mx[i] = 0.f; ls[i] = 0.f; }
     }
-    __syncthreads();
 
-    // ---- per-thread sorted top-k over the flattened (beam, word) axis -----------------------------------
+    // ---- candidates: per-lane sorted top-k over the flattened (beam, word) axis --------------------------
     float lv[kMaxK];
     int li[kMaxK];
 #pragma unroll
     for (int s = 0; s < kMaxK; ++s) { lv[s] = -INFINITY; li[s] = 0x7fffffff; }
-    for (int i = 0; i < W; ++i) {
-        const float run = p.running[b * W + i];
-        const float alive = p.alive ? p.alive[b * W + i] : 1.0f;
-        const float mx = row_max[i], ls = row_lsum[i];
-        const float* xr = x + (size_t)i * p.ld;
-        float* mrow = p.masked_logp ? p.masked_logp + ((size_t)b * W + i) * V : nullptr;
-        for (int c = tid; c < V; c += kSelThreads) {
-            const float lp = (xr[c] - mx) - ls;
-            if (mrow) mrow[c] = lp * alive;
-            // seq_mask * candidate + frozen * (1 - seq_mask), beam_search.py:52-55
-            const float frozen = c == 0 ? run : -999.0f;
-            const float cand = alive * (run + lp) + frozen * (1.0f - alive);
-            if (cand > lv[k - 1] || (cand == lv[k - 1] && i * V + c < li[k - 1])) {
-                float cv = cand;
-                int ci = i * V + c;
 #pragma unroll
-                for (int s = 0; s < kMaxK; ++s) {
-                    if (s < k && better(cv, ci, lv[s], li[s])) {
-                        const float tv = lv[s]; const int ti = li[s];
-                        lv[s] = cv; li[s] = ci; cv = tv; ci = ti;
-                    }
+    for (int i = 0; i < kRows; ++i) {
+        if (i < W) {
+            const float run = p.running[b * W + i];
+            const float alive = p.alive ? p.alive[b * W + i] : 1.0f;
+            float* mrow = p.masked_logp ? p.masked_logp + ((size_t)b * W + i) * V : nullptr;
+#pragma unroll
+            for (int j = 0; j < kPerThread; ++j) {
+                const int c = tid + j * kSelThreads;
+                if (c < V) {
+                    const float lp = (xv[i][j] - mx[i]) - ls[i];
+                    if (mrow) mrow[c] = lp * alive;
+                    // seq_mask * candidate + frozen * (1 - seq_mask), beam_search.py:52-55
+                    const float frozen = c == 0 ? run : -999.0f;
+                    const float cand = alive * (run + lp) + frozen * (1.0f - alive);
+                    if (better(cand, i * V + c, lv[k - 1], li[k - 1])) list_insert(lv, li, k, cand, i * V + c);
                 }
             }
         }
     }
 
-    // ---- k rounds of block-wide argmax over the list heads ---------------------------------------------
-    int head = 0;
-    for (int round = 0; round < k; ++round) {
-        Cand c;
-        c.v = -INFINITY; c.idx = 0x7fffffff;
+    // ---- wave top-k, one barrier, wave 0 merges the 16*k survivors ------------------------------------------
+    const Cand wbest = wave_topk(lv, li, k, lane);
+    if (lane < k) { fin_v[wave * k + lane] = wbest.v; fin_i[wave * k + lane] = wbest.idx; }
+    __syncthreads();
+    if (wave == 0) {
+        float mv[kMaxK];
+        int mi[kMaxK];
 #pragma unroll
-        for (int s = 0; s < kMaxK; ++s)
-            if (s == head) { c.v = lv[s]; c.idx = li[s]; }
-        c = wave_best(c);
-        if (lane == 0) { cand_v[wave] = c.v; cand_i[wave] = c.idx; }
-        __syncthreads();
-        if (tid == 0) {
-            float bv = cand_v[0]; int bi = cand_i[0];
-            for (int w = 1; w < 16; ++w)
-                if (better(cand_v[w], cand_i[w], bv, bi)) { bv = cand_v[w]; bi = cand_i[w]; }
-            winner_idx = bi;
-            p.chosen[b * k + round] = (int64_t)bi;
-            p.score[b * k + round] = bv;
+        for (int s = 0; s < kMaxK; ++s) { mv[s] = -INFINITY; mi[s] = 0x7fffffff; }
+        for (int e = lane; e < 16 * k; e += 64) list_insert(mv, mi, k, fin_v[e], fin_i[e]);
+        const Cand best = wave_topk(mv, mi, k, lane);
+        if (lane < k) {
+            p.chosen[b * k + lane] = (int64_t)best.idx;
+            p.score[b * k + lane] = best.v;
         }
-        __syncthreads();
-        bool mine = false;
-#pragma unroll
-        for (int s = 0; s < kMaxK; ++s)
-            if (s == head && li[s] == winner_idx) mine = true;
-        if (mine) ++head;
-        __syncthreads();
     }
-    if (tid < W && p.row_max_out) {
-        p.row_max_out[b * W + tid] = row_max[tid];
-        p.row_lsum_out[b * W + tid] = row_lsum[tid];
+    if (p.row_max_out && wave == 1 && lane < W) {
+        // mx / ls are identical in every thread; pick them with a static-index select
+        float m = 0.f, l = 0.f;
+#pragma unroll
+        for (int i = 0; i < kRows; ++i)
+            if (i == lane) { m = mx[i]; l = ls[i]; }
+        p.row_max_out[b * W + lane] = m;
+        p.row_lsum_out[b * W + lane] = l;
     }
 }
 
@@ -210,7 +258,19 @@ __global__ __launch_bounds__(256) void beam_gather_all_kernel(const float* __res
 int ovc_beam_select_launch(const BeamSelectArgs& p, int B, hipStream_t stream) {
     if (B <= 0 || p.width <= 0 || p.width > kMaxK || p.k <= 0 || p.k > kMaxK || p.V <= 0) return OVC_EINVAL;
     if ((long)p.width * p.V < p.k || (long)p.width * p.V > 0x7fffffffL) return OVC_EINVAL;
-    hipLaunchKernelGGL(beam_select_kernel, dim3(B), dim3(kSelThreads), 0, stream, p);
+    const int per_thread = (p.V + kSelThreads - 1) / kSelThreads;
+    const dim3 grid(B), block(kSelThreads);
+#define OVC_SELECT(PT, ROWS) hipLaunchKernelGGL((beam_select_kernel<PT, ROWS>), grid, block, 0, stream, p)
+    if (p.width == 1) {
+        if (per_thread <= 4) OVC_SELECT(4, 1); else if (per_thread <= 16) OVC_SELECT(16, 1); else return OVC_EINVAL;
+    } else if (p.width <= 5) {
+        if (per_thread <= 4) OVC_SELECT(4, 5); else if (per_thread <= 10) OVC_SELECT(10, 5);
+        else if (per_thread <= 16) OVC_SELECT(16, 5); else return OVC_EINVAL;
+    } else {
+        if (per_thread <= 4) OVC_SELECT(4, 8); else if (per_thread <= 10) OVC_SELECT(10, 8); else return OVC_EINVAL;
+    }
+#undef OVC_SELECT
+    // (vocabularies above 16384 words, or above 10240 with beams wider than 5, are not supported yet)
     OVC_RETURN_IF_LAUNCH_FAILED();
     return OVC_OK;
 }

@@ -29,7 +29,12 @@ namespace {
 constexpr int BK = 32;        // K depth of one LDS tile
 constexpr int LDT = BK + 4;   // padded LDS row stride (floats)
 
-template <int BM, int BN, int WM, int WN>
+// WM x WN x WK waves: the workgroup tile is split WM x WN over the output and, for small tiles, WK ways
+// over K *inside* the workgroup (each wave takes BK/8/WK of the 8-deep k-groups of every K tile; the
+// partial accumulators are summed through LDS at the end).  With M = B*k = 1280 decode rows an output
+// of 1280 x 512 is only 640 MFMA tiles for 1024 SIMDs; splitting K inside 32x32 workgroups turns that
+// into 2560 wave-sized tasks without any cross-workgroup reduction.
+template <int BM, int BN, int WM, int WN, int WK>
 struct TileConfig {
     static constexpr int kThreads = 256;
     static constexpr int kWaveM = BM / WM;         // rows per wave
@@ -38,10 +43,12 @@ struct TileConfig {
     static constexpr int TN = kWaveN / 32;
     static constexpr int kLoadA = BM * (BK / 4) / kThreads;   // float4 per thread per tile
     static constexpr int kLoadB = BN * (BK / 4) / kThreads;
+    static constexpr int kGroupsPerWave = (BK / 8) / WK;      // 8-deep k-groups per wave per K tile
     static constexpr int kLdsFloats = 2 * (BM + BN) * LDT;
-    static_assert(WM * WN == 4, "four waves per workgroup");
+    static_assert(WM * WN * WK == 4, "four waves per workgroup");
     static_assert(kWaveM % 32 == 0 && kWaveN % 32 == 0, "wave tile must be a multiple of 32x32");
     static_assert(kLoadA >= 1 && kLoadB >= 1, "tile too small for 256 loader threads");
+    static_assert((WK - 1) * BM * BN <= kLdsFloats, "K-split reduction must fit in the tile buffers");
 };
 
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
@@ -51,15 +58,16 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return base + (bid >> 3);
 }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int WK>
 __global__ __launch_bounds__(256) void gemm_f32_mfma(GemmArgs p, int tiles_m, int tiles_n_per_seg) {
-    using Cfg = TileConfig<BM, BN, WM, WN>;
+    using Cfg = TileConfig<BM, BN, WM, WN, WK>;
     extern __shared__ __attribute__((aligned(16))) float lds[];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const int wm = wave / WN, wn = wave % WN;
+    const int wk = wave / (WM * WN);
+    const int wm = (wave / WN) % WM, wn = wave % WN;
 
     const int nwg = gridDim.x;
     const int tile = xcd_remap(blockIdx.x, nwg);
@@ -156,7 +164,8 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma(GemmArgs p, int tiles_m, in
         const float* a_base = lds + buf * kBufFloats + (wm * Cfg::kWaveM + frag_row) * LDT + frag_k;
         const float* b_base = lds + buf * kBufFloats + (BM + wn * Cfg::kWaveN + frag_row) * LDT + frag_k;
 #pragma unroll
-        for (int kk = 0; kk < BK / 8; ++kk) {
+        for (int g = 0; g < Cfg::kGroupsPerWave; ++g) {
+            const int kk = wk * Cfg::kGroupsPerWave + g;
             f32x4 a[Cfg::TM], b[Cfg::TN];
 #pragma unroll
             for (int i = 0; i < Cfg::TM; ++i)
@@ -175,6 +184,33 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma(GemmArgs p, int tiles_m, in
 
         if (kt + 1 < nkt) store_tile(buf ^ 1);
         __syncthreads();
+    }
+
+    // Intra-workgroup K-split: waves wk > 0 park their partial tiles in LDS (the tile buffers are free
+    // after the last barrier), wave wk == 0 adds them and runs the epilogue.
+    if (WK > 1) {
+        float* red = lds;
+        const int wtile = wm * WN + wn;
+        if (wk > 0) {
+#pragma unroll
+            for (int i = 0; i < Cfg::TM; ++i)
+#pragma unroll
+                for (int j = 0; j < Cfg::TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        red[((((wk - 1) * (WM * WN) + wtile) * Cfg::TM * Cfg::TN + i * Cfg::TN + j) * 16 + r) * 64 + lane] = acc[i][j][r];
+        }
+        __syncthreads();
+        if (wk > 0) return;
+#pragma unroll
+        for (int s = 0; s < WK - 1; ++s)
+#pragma unroll
+            for (int i = 0; i < Cfg::TM; ++i)
+#pragma unroll
+                for (int j = 0; j < Cfg::TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        acc[i][j][r] += red[(((s * (WM * WN) + wtile) * Cfg::TM * Cfg::TN + i * Cfg::TN + j) * 16 + r) * 64 + lane];
     }
 
     // Epilogue.  D layout of the 32x32 tile: col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
@@ -221,36 +257,61 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma(GemmArgs p, int tiles_m, in
     }
 }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int WK>
 int launch_config(const GemmArgs& a, hipStream_t stream) {
-    using Cfg = TileConfig<BM, BN, WM, WN>;
+    using Cfg = TileConfig<BM, BN, WM, WN, WK>;
     const int tiles_m = (a.M + BM - 1) / BM;
     const int tiles_n = (a.seg_n + BN - 1) / BN;
     const int grid = tiles_m * tiles_n * a.nseg;
     const size_t lds_bytes = sizeof(float) * Cfg::kLdsFloats;
     static bool attr_set = false;   // raise the dynamic-LDS cap once per process (idempotent)
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f32_mfma<BM, BN, WM, WN>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f32_mfma<BM, BN, WM, WN, WK>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_f32_mfma<BM, BN, WM, WN>), dim3(grid), dim3(256), lds_bytes, stream, a, tiles_m, tiles_n);
+    hipLaunchKernelGGL((gemm_f32_mfma<BM, BN, WM, WN, WK>), dim3(grid), dim3(256), lds_bytes, stream, a, tiles_m, tiles_n);
     OVC_RETURN_IF_LAUNCH_FAILED();
     return OVC_OK;
 }
 
-// Estimated cost (in units of 32x32x32 MFMA blocks per SIMD) of a tiling on 256 CUs: rounds of
-// workgroups times the MFMA work one wave does per workgroup.
-template <int BM, int BN>
-double tiling_cost(const GemmArgs& a) {
-    const long tiles = (long)((a.M + BM - 1) / BM) * ((a.seg_n + BN - 1) / BN) * a.nseg;
-    const long resident = 256L * ((BM + BN) * LDT * 8 <= 40 * 1024 ? 2 : 1);
-    const long rounds = (tiles + resident - 1) / resident;
-    const double per_wg = (double)(BM / 32) * (BN / 32) / 4.0 + 0.35;   // + fixed per-tile overhead
-    return rounds * per_wg * ((BM + BN) * LDT * 8 <= 40 * 1024 ? 2.0 : 1.0);
+struct TilingInfo { int bm, bn, wk; };
+constexpr TilingInfo kTilings[] = {
+    {128, 128, 1},   // 0
+    {64, 128, 1},    // 1
+    {128, 64, 1},    // 2
+    {64, 64, 1},     // 3
+    {32, 64, 2},     // 4
+    {64, 32, 2},     // 5
+    {32, 32, 4},     // 6
+};
+constexpr int kNumTilings = sizeof(kTilings) / sizeof(kTilings[0]);
+
+int g_forced_tiling = -1;   // tuning hook (ovc_debug_force_gemm_tiling); -1 = automatic
+
+// Predicted time of a tiling in MFMA-issue units (one unit = one v_mfma_f32_32x32x2_f32 slot of a
+// SIMD): every SIMD of a CU executes the waves of the workgroups resident on that CU, so the critical
+// path is ceil(workgroups / 256 CUs) * (MFMAs one wave issues per workgroup), plus a per-workgroup
+// overhead (prologue load, epilogue, barriers) that smaller tiles pay more often, plus a bandwidth
+// term for tiles whose operand traffic per FLOP is high.
+double tiling_cost(const GemmArgs& a, const TilingInfo& t) {
+    const int K = a.K1 + a.K2;
+    const long wgs = (long)((a.M + t.bm - 1) / t.bm) * ((a.seg_n + t.bn - 1) / t.bn) * a.nseg;
+    const double per_cu = (double)((wgs + 255) / 256);                       // workgroups on the busiest CU
+    const double mfma_per_wave = (double)(t.bm / 32) * (t.bn / 32) * (K / 2.0) / 4.0;
+    const double overhead = 48.0;                                            // ~3k cycles of non-MFMA time per workgroup
+    const double bytes_per_flop = 2.0 * (t.bm + t.bn) / (double)(t.bm * t.bn);   // operand floats per MAC
+    const double bw_penalty = 1.0 + 4.0 * bytes_per_flop;                    // 128x128: 1.06, 32x32: 1.5
+    return per_cu * (mfma_per_wave * bw_penalty + overhead);
 }
 
 }  // namespace
+
+extern "C" int ovc_debug_force_gemm_tiling(int tiling) {
+    if (tiling < -1 || tiling >= kNumTilings) return OVC_EINVAL;
+    g_forced_tiling = tiling;
+    return OVC_OK;
+}
 
 int ovc_gemm_launch(const GemmArgs& a, hipStream_t stream) {
     const int K = a.K1 + a.K2;
@@ -261,26 +322,28 @@ int ovc_gemm_launch(const GemmArgs& a, hipStream_t stream) {
     if (a.K2 > 0 && (a.K1 % BK)) return OVC_EINVAL;      // the A1|A2 seam must fall on a K-tile boundary
     for (int s = 0; s < a.nseg; ++s)
         if (!a.seg[s].W || !a.seg[s].C || !ovc_aligned16(a.seg[s].W)) return OVC_EINVAL;
+    if (a.nseg > 1 && a.seg_n % 64) return OVC_EINVAL;   // a tile may not straddle two segments
 
-    // A tile may not straddle two segments.
-    const bool ok128 = a.nseg == 1 || a.seg_n % 128 == 0;
-    const bool ok64 = a.nseg == 1 || a.seg_n % 64 == 0;
-    if (!ok64) return OVC_EINVAL;
-
-    double best = 1e300;
-    int pick = 0;
-    auto consider = [&](int id, double cost, bool allowed) {
-        if (allowed && cost < best) { best = cost; pick = id; }
-    };
-    consider(0, tiling_cost<128, 128>(a), ok128);
-    consider(1, tiling_cost<64, 128>(a), ok128);
-    consider(2, tiling_cost<128, 64>(a), true);
-    consider(3, tiling_cost<64, 64>(a), true);
+    int pick = -1;
+    if (g_forced_tiling >= 0 && (a.nseg == 1 || a.seg_n % kTilings[g_forced_tiling].bn == 0)) {
+        pick = g_forced_tiling;
+    } else {
+        double best = 1e300;
+        for (int i = 0; i < kNumTilings; ++i) {
+            if (a.nseg > 1 && a.seg_n % kTilings[i].bn) continue;
+            const double c = tiling_cost(a, kTilings[i]);
+            if (c < best) { best = c; pick = i; }
+        }
+    }
     switch (pick) {
-        case 0: return launch_config<128, 128, 2, 2>(a, stream);
-        case 1: return launch_config<64, 128, 2, 2>(a, stream);
-        case 2: return launch_config<128, 64, 2, 2>(a, stream);
-        default: return launch_config<64, 64, 2, 2>(a, stream);
+        case 0: return launch_config<128, 128, 2, 2, 1>(a, stream);
+        case 1: return launch_config<64, 128, 2, 2, 1>(a, stream);
+        case 2: return launch_config<128, 64, 2, 2, 1>(a, stream);
+        case 3: return launch_config<64, 64, 2, 2, 1>(a, stream);
+        case 4: return launch_config<32, 64, 1, 2, 2>(a, stream);
+        case 5: return launch_config<64, 32, 2, 1, 2>(a, stream);
+        case 6: return launch_config<32, 32, 1, 1, 4>(a, stream);
+        default: return OVC_EINVAL;
     }
 }
 

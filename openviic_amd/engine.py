@@ -1,8 +1,8 @@
 """Python handle of the fused HIP engine (``ovc_encode`` / ``ovc_beam_search``).
 
 ``CaptionEngine`` reads the parameter tensors of a host-side model (``architectures.py``) into the
-``ovc_model`` pointer table once, owns a cached device workspace and forwards calls on the current
-HIP stream.  Parameters are referenced, not copied: in-place updates of the tensors are seen by
+``ovc_model`` pointer table once, owns one cached device workspace per HIP stream and forwards
+calls on the current stream -- independent batches issued on different streams overlap on the GPU.  Parameters are referenced, not copied: in-place updates of the tensors are seen by
 the engine; re-allocation (``.to()``) drops the engine (``BaseTransformer._apply``).
 """
 import ctypes
@@ -52,7 +52,7 @@ class CaptionEngine:
         self.model = model
         self._keep = []          # tensors created here whose storage the pointer table references
         self.desc = self._describe(model)
-        self._workspace = None
+        self._workspaces = {}    # one scratch buffer per HIP stream: concurrent batches never share state
         self.device = next(model.parameters()).device
         if self.device.type != "cuda":
             raise native.OvcError("the fused engine needs the model on a HIP device (got {}); "
@@ -109,10 +109,12 @@ class CaptionEngine:
         if need == 0:
             raise native.OvcError("unsupported engine configuration (B={}, N={}, beam={}; see ovc_workspace_bytes)"
                                   .format(B, N, k))
-        if self._workspace is None or self._workspace.numel() < need:
-            self._workspace = None
-            self._workspace = torch.empty(need, dtype=torch.uint8, device=self.device)
-        return self._workspace, need
+        key = torch.cuda.current_stream().cuda_stream
+        ws = self._workspaces.get(key)
+        if ws is None or ws.numel() < need:
+            self._workspaces.pop(key, None)
+            ws = self._workspaces[key] = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return ws, need
 
     @staticmethod
     def _features(x, name):
