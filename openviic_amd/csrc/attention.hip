@@ -192,67 +192,92 @@ extern "C" int ovc_attention(const float* q, const float* k, const float* v, int
 // Decode-time attention (engine only)
 // =================================================================================================
 
+// One workgroup per beam row, all heads at once.
+//   phase 0  the row's ancestor slots and pad flags for positions 0..t go to LDS (breaks the dependent
+//            anc -> K load chain: every K/V load below is independent and can be in flight together)
+//   phase 1  wave w takes keys w, w+4, ...: a key row [h*dk] is read fully coalesced (float4 per lane,
+//            256 floats per instruction), multiplied with the matching q registers and reduced inside
+//            each head's dk/4-lane group by shuffles -> sc[head][key]
+//   phase 2  softmax over the t+1 keys of each head (one wave per head, lane = key)
+//   phase 3  out = P V: thread = (float4 column, key group); groups are combined through LDS
+constexpr int kSelfMaxHeads = 32;
+
 __global__ __launch_bounds__(256) void decode_self_attention_kernel(DecodeSelfArgs p) {
-    __shared__ float sc[4][64];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int r = blockIdx.x;
-    const int g = lane >> 4, c = lane & 15;
-    const int t = p.t;
-    const float scale_div = sqrtf((float)p.dk);
-    for (int hd = wave; hd < p.h; hd += 4) {
-        f32x4 q4 = {0.f, 0.f, 0.f, 0.f};
-        if (4 * c < p.dk) q4 = *reinterpret_cast<const f32x4*>(p.q + (size_t)r * p.ldq + hd * p.dk + 4 * c);
-        for (int j0 = 0; j0 <= t; j0 += 4) {
-            const int j = j0 + g;
-            float part = 0.f;
-            int slot = 0;
-            if (j <= t) {
-                slot = (j == t) ? r : p.anc[(size_t)r * p.anc_ld + j];
-                if (4 * c < p.dk) {
-                    const f32x4 k4 = *reinterpret_cast<const f32x4*>(p.kcache + (size_t)j * p.pos_stride + (size_t)slot * p.ldkv + hd * p.dk + 4 * c);
-                    part = (q4[0] * k4[0] + q4[1] * k4[1]) + (q4[2] * k4[2] + q4[3] * k4[3]);
-                }
-            }
-            part += __shfl_xor(part, 1, 64);
-            part += __shfl_xor(part, 2, 64);
-            part += __shfl_xor(part, 4, 64);
-            part += __shfl_xor(part, 8, 64);
-            if (j <= t && c == 0) {
-                float s = part / scale_div;
-                if (p.padflag[(size_t)j * p.pad_ld + slot]) s = -INFINITY;
-                sc[wave][j] = s;
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
-        {   // softmax over the t+1 scores (t < 64)
-            const float s = lane <= t ? sc[wave][lane] : -INFINITY;
-            const float mx = wave_max(s);
-            const float e = lane <= t ? expf(s - mx) : 0.f;
-            const float sum = wave_sum(e);
-            if (lane <= t) sc[wave][lane] = e / sum;
-        }
-        __builtin_amdgcn_wave_barrier();
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        for (int j0 = 0; j0 <= t; j0 += 4) {
-            const int j = j0 + g;
-            if (j <= t && 4 * c < p.dv) {
-                const int slot = (j == t) ? r : p.anc[(size_t)r * p.anc_ld + j];
-                const f32x4 v4 = *reinterpret_cast<const f32x4*>(p.vcache + (size_t)j * p.pos_stride + (size_t)slot * p.ldkv + hd * p.dv + 4 * c);
-                acc += v4 * sc[wave][j];
-            }
-        }
+    __shared__ int slots[64];
+    __shared__ uint8_t pads[64];
+    __shared__ float sc[kSelfMaxHeads][64];
+    __shared__ __attribute__((aligned(16))) float red[256 * 4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = blockIdx.x, t = p.t;
+    const int hk = p.h * p.dk;                       // == h * dv (checked on the host)
+    const int chunks = (hk + 255) >> 8;              // float4-per-lane instructions per key row
+
+    if (tid <= t) {
+        const int slot = tid == t ? r : p.anc[(size_t)r * p.anc_ld + tid];
+        slots[tid] = slot;
+        pads[tid] = p.padflag[(size_t)tid * p.pad_ld + slot];
+    }
+    f32x4 q4[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            acc[e] += __shfl_xor(acc[e], 16, 64);
-            acc[e] += __shfl_xor(acc[e], 32, 64);
+    for (int c = 0; c < 4; ++c) {
+        const int e = c * 256 + lane * 4;
+        q4[c] = (c < chunks && e < hk) ? *reinterpret_cast<const f32x4*>(p.q + (size_t)r * p.ldq + e) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    __syncthreads();
+
+    const int group = p.dk >> 2;                     // lanes per head: a power of two <= 16
+    const float scale_div = sqrtf((float)p.dk);
+    for (int j = wave; j <= t; j += 4) {
+        const float* krow = p.kcache + (size_t)j * p.pos_stride + (size_t)slots[j] * p.ldkv;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            if (c < chunks) {
+                const int e = c * 256 + lane * 4;
+                float part = 0.f;
+                if (e < hk) {
+                    const f32x4 k4 = *reinterpret_cast<const f32x4*>(krow + e);
+                    part = (q4[c][0] * k4[0] + q4[c][1] * k4[1]) + (q4[c][2] * k4[2] + q4[c][3] * k4[3]);
+                }
+                for (int off = 1; off < group; off <<= 1) part += __shfl_xor(part, off, 64);
+                if (e < hk && (lane & (group - 1)) == 0) sc[e / p.dk][j] = pads[j] ? -INFINITY : part / scale_div;
+            }
         }
-        if (g == 0 && 4 * c < p.dv) *reinterpret_cast<f32x4*>(p.out + (size_t)r * p.ldo + hd * p.dv + 4 * c) = acc;
-        __builtin_amdgcn_wave_barrier();
+    }
+    __syncthreads();
+
+    for (int hd = wave; hd < p.h; hd += 4) {
+        const float s = lane <= t ? sc[hd][lane] : -INFINITY;
+        const float mx = wave_max(s);
+        const float e = lane <= t ? expf(s - mx) : 0.f;
+        const float sum = wave_sum(e);
+        if (lane <= t) sc[hd][lane] = e / sum;
+    }
+    __syncthreads();
+
+    const int cols = hk >> 2;                        // float4 columns of the output row (<= 256)
+    const int groups = 256 / cols;                   // key groups working in parallel
+    const int col = tid % cols, g = tid / cols;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    if (g < groups) {
+        const int hd = (col * 4) / p.dv;
+        for (int j = g; j <= t; j += groups) {
+            const f32x4 v4 = *reinterpret_cast<const f32x4*>(p.vcache + (size_t)j * p.pos_stride + (size_t)slots[j] * p.ldkv + col * 4);
+            acc += v4 * sc[hd][j];
+        }
+        if (g > 0) *reinterpret_cast<f32x4*>(red + (size_t)tid * 4) = acc;
+    }
+    __syncthreads();
+    if (g == 0) {
+        for (int gg = 1; gg < groups; ++gg) acc += *reinterpret_cast<const f32x4*>(red + (size_t)(gg * cols + col) * 4);
+        *reinterpret_cast<f32x4*>(p.out + (size_t)r * p.ldo + col * 4) = acc;
     }
 }
 
 int ovc_decode_self_attention(const DecodeSelfArgs& p, int rows, hipStream_t stream) {
-    if (p.t < 0 || p.t >= 64 || p.dk > 64 || p.dv > 64 || (p.dk & 3) || (p.dv & 3)) return OVC_EINVAL;
+    const int hk = p.h * p.dk;
+    if (p.t < 0 || p.t >= 64 || p.h <= 0 || p.h > kSelfMaxHeads) return OVC_EINVAL;
+    if (p.dk != p.dv || (p.dk & (p.dk - 1)) || p.dk < 4 || p.dk > 64) return OVC_EINVAL;   // dk in {4,8,16,32,64}
+    if (hk > 1024 || 256 % (hk >> 2)) return OVC_EINVAL;                                   // h*dk in {64,128,256,512,1024}
     hipLaunchKernelGGL(decode_self_attention_kernel, dim3(rows), dim3(256), 0, stream, p);
     OVC_RETURN_IF_LAUNCH_FAILED();
     return OVC_OK;

@@ -18,6 +18,7 @@ namespace {
 
 constexpr int kSelThreads = 1024;
 constexpr int kMaxK = OVC_MAX_BEAM;
+constexpr int kSurvivorCap = 2048;   // LDS list of candidates that can still reach the top k
 
 struct Cand { float v; int idx; };
 
@@ -65,14 +66,17 @@ __device__ __forceinline__ Cand wave_topk(const float (&lv)[kMaxK], const int (&
 
 // One workgroup (1024 threads = 16 waves) per image.  The image's width*V logits are read from
 // memory exactly once into registers (all loads in flight together: the kernel is latency-bound, not
-// bandwidth-bound), the log-sum-exp of every live row and the candidate scores are computed from those
-// registers, each wave reduces its lanes' lists to the wave's k best with shuffles, and after a single
-// barrier wave 0 merges the 16*k survivors.
+// bandwidth-bound); the log-sum-exp of every live row and the candidate scores are computed from those
+// registers.  Selection is threshold based: the k-th best of a wave's lane maxima bounds the k-th best
+// overall from below, so only the handful of candidates at or above that bound are collected (LDS list)
+// and ranked by one wave -- no per-candidate sorted-list maintenance on the hot path.
 template <int kPerThread, int kRows>
 __global__ __launch_bounds__(kSelThreads) void beam_select_kernel(BeamSelectArgs p) {
     __shared__ float red_max[16][kMaxK], red_sum[16][kMaxK];
-    __shared__ float fin_v[16 * kMaxK];
-    __shared__ int fin_i[16 * kMaxK];
+    __shared__ float thr[16];
+    __shared__ int count;
+    __shared__ float surv_v[kSurvivorCap];
+    __shared__ int surv_i[kSurvivorCap];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.x;
     const int W = p.width, V = p.V, k = p.k;
@@ -133,11 +137,9 @@ __global__ __launch_bounds__(kSelThreads) void beam_select_kernel(BeamSelectArgs
         for (int i = 0; i < kRows; ++i) { mx[i] = 0.f; ls[i] = 0.f; }
     }
 
-    // ---- candidates: per-lane sorted top-k over the flattened (beam, word) axis --------------------------
-    float lv[kMaxK];
-    int li[kMaxK];
-#pragma unroll
-    for (int s = 0; s < kMaxK; ++s) { lv[s] = -INFINITY; li[s] = 0x7fffffff; }
+    // ---- candidate scores (kept in the logit registers) and each lane's best -------------------------------
+    float bv = -INFINITY;
+    int bi = 0x7fffffff;
 #pragma unroll
     for (int i = 0; i < kRows; ++i) {
         if (i < W) {
@@ -147,32 +149,100 @@ __global__ __launch_bounds__(kSelThreads) void beam_select_kernel(BeamSelectArgs
 #pragma unroll
             for (int j = 0; j < kPerThread; ++j) {
                 const int c = tid + j * kSelThreads;
+                float cand = -INFINITY;
                 if (c < V) {
                     const float lp = (xv[i][j] - mx[i]) - ls[i];
                     if (mrow) mrow[c] = lp * alive;
                     // seq_mask * candidate + frozen * (1 - seq_mask), beam_search.py:52-55
                     const float frozen = c == 0 ? run : -999.0f;
-                    const float cand = alive * (run + lp) + frozen * (1.0f - alive);
-                    if (better(cand, i * V + c, lv[k - 1], li[k - 1])) list_insert(lv, li, k, cand, i * V + c);
+                    cand = alive * (run + lp) + frozen * (1.0f - alive);
+                    if (better(cand, i * V + c, bv, bi)) { bv = cand; bi = i * V + c; }
                 }
+                xv[i][j] = cand;
             }
         }
     }
 
-    // ---- wave top-k, one barrier, wave 0 merges the 16*k survivors ------------------------------------------
-    const Cand wbest = wave_topk(lv, li, k, lane);
-    if (lane < k) { fin_v[wave * k + lane] = wbest.v; fin_i[wave * k + lane] = wbest.idx; }
+    // ---- a lower bound T on the k-th best: the k-th best of one wave's lane maxima (k distinct
+    //      candidates are >= it), tightened by taking the largest such bound over the 16 waves -----------------
+    {
+        float cv = bv;
+        int ci = bi;
+        float kth = -INFINITY;
+        for (int round = 0; round < k; ++round) {
+            Cand c; c.v = cv; c.idx = ci;
+            const Cand w = wave_best(c);
+            kth = w.idx != 0x7fffffff ? w.v : -INFINITY;
+            if (ci == w.idx) { cv = -INFINITY; ci = 0x7fffffff; }
+        }
+        if (lane == 0) thr[wave] = kth;
+        if (tid == 0) count = 0;
+    }
     __syncthreads();
-    if (wave == 0) {
-        float mv[kMaxK];
-        int mi[kMaxK];
+    float T = thr[0];
 #pragma unroll
-        for (int s = 0; s < kMaxK; ++s) { mv[s] = -INFINITY; mi[s] = 0x7fffffff; }
-        for (int e = lane; e < 16 * k; e += 64) list_insert(mv, mi, k, fin_v[e], fin_i[e]);
-        const Cand best = wave_topk(mv, mi, k, lane);
-        if (lane < k) {
-            p.chosen[b * k + lane] = (int64_t)best.idx;
-            p.score[b * k + lane] = best.v;
+    for (int w = 1; w < 16; ++w) T = fmaxf(T, thr[w]);
+
+    // ---- survivors (score >= T; usually a few dozen) are appended to an LDS list --------------------------------
+#pragma unroll
+    for (int i = 0; i < kRows; ++i) {
+        if (i < W) {
+#pragma unroll
+            for (int j = 0; j < kPerThread; ++j) {
+                if (tid + j * kSelThreads < V && xv[i][j] >= T) {
+                    const int pos = atomicAdd(&count, 1);
+                    if (pos < kSurvivorCap) { surv_v[pos] = xv[i][j]; surv_i[pos] = i * V + tid + j * kSelThreads; }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    const int nsurv = count;
+    if (nsurv <= kSurvivorCap) {
+        if (wave == 0) {
+            float mv[kMaxK];
+            int mi[kMaxK];
+#pragma unroll
+            for (int s = 0; s < kMaxK; ++s) { mv[s] = -INFINITY; mi[s] = 0x7fffffff; }
+            for (int e = lane; e < nsurv; e += 64) list_insert(mv, mi, k, surv_v[e], surv_i[e]);
+            const Cand best = wave_topk(mv, mi, k, lane);
+            if (lane < k) {
+                p.chosen[b * k + lane] = (int64_t)best.idx;
+                p.score[b * k + lane] = best.v;
+            }
+        }
+    } else {
+        // Massive ties (e.g. a live beam fed <pad> yields a uniform row: V equal scores).  Exhaustive path:
+        // per-lane sorted lists over all candidates, wave top-k, merge by wave 0.
+        float lv[kMaxK];
+        int li[kMaxK];
+#pragma unroll
+        for (int s = 0; s < kMaxK; ++s) { lv[s] = -INFINITY; li[s] = 0x7fffffff; }
+#pragma unroll
+        for (int i = 0; i < kRows; ++i) {
+            if (i < W) {
+#pragma unroll
+                for (int j = 0; j < kPerThread; ++j) {
+                    const int idx = i * V + tid + j * kSelThreads;
+                    if (tid + j * kSelThreads < V && better(xv[i][j], idx, lv[k - 1], li[k - 1])) list_insert(lv, li, k, xv[i][j], idx);
+                }
+            }
+        }
+        const Cand wbest = wave_topk(lv, li, k, lane);
+        __syncthreads();                       // the survivor list is dead: reuse its head as the merge buffer
+        if (lane < k) { surv_v[wave * k + lane] = wbest.v; surv_i[wave * k + lane] = wbest.idx; }
+        __syncthreads();
+        if (wave == 0) {
+            float mv[kMaxK];
+            int mi[kMaxK];
+#pragma unroll
+            for (int s = 0; s < kMaxK; ++s) { mv[s] = -INFINITY; mi[s] = 0x7fffffff; }
+            for (int e = lane; e < 16 * k; e += 64) list_insert(mv, mi, k, surv_v[e], surv_i[e]);
+            const Cand best = wave_topk(mv, mi, k, lane);
+            if (lane < k) {
+                p.chosen[b * k + lane] = (int64_t)best.idx;
+                p.score[b * k + lane] = best.v;
+            }
         }
     }
     if (p.row_max_out && wave == 1 && lane < W) {

@@ -237,3 +237,29 @@ def test_beam_select(B, W, V, k):
     np.testing.assert_array_equal(chosen.cpu().numpy(), want_idx.numpy())
     np.testing.assert_array_equal(score.cpu().numpy(), want_val.numpy())       # same fp32 expression: bit-exact
     np.testing.assert_array_equal(masked.cpu().numpy(), want_masked.numpy())
+
+
+def test_beam_select_massive_ties_take_lowest_indices():
+    """A live beam fed <pad> yields a uniform row: thousands of exactly equal candidates.  The engine's
+    rule is "lower flat (beam, word) index first" (stable order); this drives the exhaustive fallback."""
+    from openviic_amd import native
+    lib = native.load()
+    B, W, V, k = 3, 5, 10201, 5
+    logp = torch.full((B, W, V), -9.230241775512695)          # -log(10201) in fp32, every word
+    g = torch.Generator().manual_seed(4)
+    logp[1] = torch.log_softmax(torch.randn(W, V, generator=g), -1)
+    logp[1, 2] = -9.230241775512695                               # one uniform beam among normal ones
+    running = torch.zeros(B, W)
+    running[1] = torch.tensor([-3.0, -3.5, 0.5, -4.0, -2.0])       # the uniform beam leads: its words 0..4 win
+    running[2] = torch.tensor([-1.0, -1.0, -1.0, -1.0, -1.0])
+    alive = torch.ones(B, W)
+    want_idx, want_val, _ = _select_ref(logp, running, alive, k)
+    d = lambda t: t.to(DEV).contiguous()
+    lp, rn, al = d(logp), d(running), d(alive)
+    chosen = torch.empty(B, k, dtype=torch.int64, device=DEV)
+    score = torch.empty(B, k, device=DEV)
+    assert lib.ovc_beam_select(lp.data_ptr(), rn.data_ptr(), al.data_ptr(), B, W, V, k, chosen.data_ptr(),
+                               score.data_ptr(), None, native.stream_handle()) == 0
+    np.testing.assert_array_equal(chosen.cpu().numpy(), want_idx.numpy())
+    np.testing.assert_array_equal(score.cpu().numpy(), want_val.numpy())
+    assert chosen[0].tolist() == [0, 1, 2, 3, 4] and chosen[1].tolist() == [2 * V + i for i in range(5)]
