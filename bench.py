@@ -50,7 +50,7 @@ def parse():
     ap.add_argument("--config", default="standard_transformer")
     ap.add_argument("--batch", type=int, default=256, help="images per GPU per step")
     ap.add_argument("--beam", type=int, default=5)
-    ap.add_argument("--streams", type=int, default=2,
+    ap.add_argument("--streams", type=int, default=3,
                     help="HIP streams that consecutive (independent) batches alternate on; decode steps are "
                          "small launches, so two batches in flight fill the chip better than one")
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -250,7 +250,7 @@ def test_beam_select_massive_ties_take_lowest_indices():
     logp[1] = torch.log_softmax(torch.randn(W, V, generator=g), -1)
     logp[1, 2] = -9.230241775512695                               # one uniform beam among normal ones
     running = torch.zeros(B, W)
-    running[1] = torch.tensor([-3.0, -3.5, 0.5, -4.0, -2.0])       # the uniform beam leads: its words 0..4 win
+    running[1] = torch.tensor([-3.0, -3.5, 9.0, -4.0, -2.0])       # the uniform beam leads: its words 0..4 win
     running[2] = torch.tensor([-1.0, -1.0, -1.0, -1.0, -1.0])
     alive = torch.ones(B, W)
     want_idx, want_val, _ = _select_ref(logp, running, alive, k)
