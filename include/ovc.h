@@ -182,18 +182,31 @@ int ovc_beam_search(const ovc_model* m, const float* features, const float* boxe
                     int k, int out_size, void* workspace, size_t workspace_bytes,
                     int64_t* ids_out, float* logp_out, float* all_logp_out, ovc_stream stream);
 
-/* Optional per-kernel-class device timing of the next engine calls (bench.py's roofline leg):
- * while enabled, every GEMM launch of the engine is bracketed by hipEvents on `stream`.
- * ovc_profile_read synchronises those events and returns launches, total milliseconds and
- * total algorithmic FLOPs (2*M*N*K) per GEMM class (0 feature proj, 1 encoder, 2 decoder
- * projections/FFN, 3 vocabulary). */
+/* Optional device timing of the engine's GEMM launches (bench.py's roofline leg).  While enabled,
+ * every GEMM launch is bracketed by hipEvents on its launch stream; the bracket's own overhead is
+ * calibrated with empty event pairs and subtracted.  ovc_profile_read synchronises the events and
+ * returns launches, total milliseconds and total algorithmic FLOPs (2*M*N*K), either per GEMM
+ * class (kind 0: 0 feature projection, 1 encoder, 2 decoder projections/FFN, 3 vocabulary) or per
+ * kernel instance (kind 1: tiling index, name from ovc_profile_kernel_name).  Enabling resets. */
 #define OVC_PROFILE_CLASSES 4
 int ovc_profile_enable(int on);
-int ovc_profile_read(int cls, int64_t* launches, double* total_ms, double* total_flops);
+int ovc_profile_read(int kind, int index, int64_t* launches, double* total_ms, double* total_flops);
+double ovc_profile_overhead_ms(void);
+const char* ovc_profile_kernel_name(int tiling);   /* "" past the last tiling */
+
+/* Measure every GEMM tiling on the shape y[M, nseg*seg_n] = x[M,K] W^T (nseg weight segments of
+ * seg_n rows) and remember the fastest for this process; later ovc_linear / engine GEMMs of that
+ * shape use it.  scratch: >= 4*(M*K + nseg*seg_n*K + M*nseg*seg_n) + 64 bytes of device memory
+ * (contents are used as operands).  SYNCHRONISES the stream -- set-up time only. */
+int ovc_gemm_tune(int M, int seg_n, int nseg, int K, void* scratch, size_t scratch_bytes,
+                  ovc_stream stream);
 
 /* Tuning hook (tools/gemm_bench.py): force GEMM tiling 0..6 (see csrc/gemm.hip) for every
  * following ovc_linear / engine GEMM in this process; -1 restores the automatic choice. */
 int ovc_debug_force_gemm_tiling(int tiling);
+/* `iters` back-to-back launches of y = x W^T + bias (x [M,K], W [N,K]) with no host work between. */
+int ovc_debug_repeat_linear(const float* x, int K, const float* W, const float* bias, float* y,
+                            int M, int N, int iters, ovc_stream stream);
 
 #ifdef __cplusplus
 }

@@ -11,6 +11,7 @@
 //     (attentions.py:297-302);
 //   * beam re-ordering is an ancestor-slot table (int32 [rows, T]) read by the self-attention
 //     kernel; the reference physically gathers every cache (beam_search.py:19-34).
+#include <algorithm>
 #include <vector>
 
 #include "common.h"
@@ -26,9 +27,45 @@ namespace {
 // ---------------------------------------------------------------------------------------------
 // opt-in GEMM timing (bench.py roofline leg)
 // ---------------------------------------------------------------------------------------------
-struct ProfileRecord { hipEvent_t start, stop; double flops; };
+struct ProfileRecord { hipEvent_t start, stop; double flops; int cls, tiling; };
+struct ProfileBin { int64_t launches; double ms, flops; };
+constexpr int kProfileTilings = 16;
 bool g_profile_on = false;
-std::vector<ProfileRecord> g_profile[OVC_PROFILE_CLASSES];
+std::vector<ProfileRecord> g_profile;            // open records (events not yet resolved)
+std::vector<ProfileRecord> g_profile_empty;      // back-to-back event pairs: the bracket's own overhead
+ProfileBin g_by_class[OVC_PROFILE_CLASSES], g_by_tiling[kProfileTilings];
+double g_profile_overhead_ms = 0.0;
+
+void profile_resolve() {
+    if (g_profile.empty() && g_profile_empty.empty()) return;
+    std::vector<float> empties;
+    for (ProfileRecord& r : g_profile_empty) {
+        (void)hipEventSynchronize(r.stop);
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, r.start, r.stop) == hipSuccess) empties.push_back(ms);
+        (void)hipEventDestroy(r.start); (void)hipEventDestroy(r.stop);
+    }
+    g_profile_empty.clear();
+    if (!empties.empty()) {
+        std::sort(empties.begin(), empties.end());
+        g_profile_overhead_ms = empties[empties.size() / 2];
+    }
+    for (ProfileRecord& r : g_profile) {
+        (void)hipEventSynchronize(r.stop);
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, r.start, r.stop) == hipSuccess) {
+            const double net = ms > g_profile_overhead_ms ? ms - g_profile_overhead_ms : 0.0;
+            ProfileBin& c = g_by_class[r.cls];
+            c.launches += 1; c.ms += net; c.flops += r.flops;
+            if (r.tiling >= 0 && r.tiling < kProfileTilings) {
+                ProfileBin& t = g_by_tiling[r.tiling];
+                t.launches += 1; t.ms += net; t.flops += r.flops;
+            }
+        }
+        (void)hipEventDestroy(r.start); (void)hipEventDestroy(r.stop);
+    }
+    g_profile.clear();
+}
 
 // ---------------------------------------------------------------------------------------------
 // workspace carving
@@ -158,13 +195,25 @@ struct Engine {
 
     int gemm(GemmArgs& a) {
         if (!g_profile_on) return ovc_gemm_launch(a, stream);
+        if (g_profile.empty() && g_profile_empty.empty()) {
+            // calibrate the bracket: event pairs with nothing in between
+            for (int i = 0; i < 16; ++i) {
+                ProfileRecord e{};
+                if (hipEventCreate(&e.start) != hipSuccess || hipEventCreate(&e.stop) != hipSuccess) return OVC_ELAUNCH;
+                (void)hipEventRecord(e.start, stream);
+                (void)hipEventRecord(e.stop, stream);
+                g_profile_empty.push_back(e);
+            }
+        }
         ProfileRecord rec{};
         if (hipEventCreate(&rec.start) != hipSuccess || hipEventCreate(&rec.stop) != hipSuccess) return OVC_ELAUNCH;
         rec.flops = 2.0 * a.M * (double)a.seg_n * a.nseg * (a.K1 + a.K2);
+        rec.cls = gemm_class;
+        rec.tiling = ovc_gemm_pick_tiling(a);
         (void)hipEventRecord(rec.start, stream);
         const int rc = ovc_gemm_launch(a, stream);
         (void)hipEventRecord(rec.stop, stream);
-        g_profile[gemm_class].push_back(rec);
+        g_profile.push_back(rec);
         return rc;
     }
 
@@ -422,22 +471,27 @@ extern "C" int ovc_beam_search(const ovc_model* m, const float* features, const 
 }
 
 extern "C" int ovc_profile_enable(int on) {
+    if (on && !g_profile_on) {
+        profile_resolve();
+        for (ProfileBin& b : g_by_class) b = ProfileBin{};
+        for (ProfileBin& b : g_by_tiling) b = ProfileBin{};
+    }
     g_profile_on = on != 0;
     return OVC_OK;
 }
 
-extern "C" int ovc_profile_read(int cls, int64_t* launches, double* total_ms, double* total_flops) {
-    if (cls < 0 || cls >= OVC_PROFILE_CLASSES || !launches || !total_ms || !total_flops) return OVC_EINVAL;
-    *launches = 0; *total_ms = 0.0; *total_flops = 0.0;
-    for (ProfileRecord& r : g_profile[cls]) {
-        (void)hipEventSynchronize(r.stop);
-        float ms = 0.f;
-        if (hipEventElapsedTime(&ms, r.start, r.stop) == hipSuccess) {
-            *launches += 1; *total_ms += ms; *total_flops += r.flops;
-        }
-        (void)hipEventDestroy(r.start);
-        (void)hipEventDestroy(r.stop);
-    }
-    g_profile[cls].clear();
+extern "C" int ovc_profile_read(int kind, int index, int64_t* launches, double* total_ms, double* total_flops) {
+    if (!launches || !total_ms || !total_flops) return OVC_EINVAL;
+    if (kind == 0 ? (index < 0 || index >= OVC_PROFILE_CLASSES) : (kind != 1 || index < 0 || index >= kProfileTilings)) return OVC_EINVAL;
+    profile_resolve();
+    const ProfileBin& b = kind == 0 ? g_by_class[index] : g_by_tiling[index];
+    *launches = b.launches; *total_ms = b.ms; *total_flops = b.flops;
     return OVC_OK;
 }
+
+extern "C" double ovc_profile_overhead_ms(void) {
+    profile_resolve();
+    return g_profile_overhead_ms;
+}
+
+extern "C" const char* ovc_profile_kernel_name(int tiling) { return ovc_gemm_tiling_name(tiling); }

@@ -22,20 +22,23 @@
 //     re-used from that XCD's L2 by the other M tiles.
 //   * Segments: N may be split into up to 8 equal segments with their own weight / bias /
 //     output pointers (fused q|k|v projections writing straight into the K/V caches).
+#include <vector>
+
 #include "common.h"
 
 namespace {
 
-constexpr int BK = 32;        // K depth of one LDS tile
-constexpr int LDT = BK + 4;   // padded LDS row stride (floats)
+// K depth of one LDS tile is a template parameter BK (32 or 64); rows are padded to BK + 4 floats:
+// 36 r mod 64 and 68 r mod 64 both hit 16 distinct 4-bank slots for 16 rows distinct mod 16.
 
 // WM x WN x WK waves: the workgroup tile is split WM x WN over the output and, for small tiles, WK ways
 // over K *inside* the workgroup (each wave takes BK/8/WK of the 8-deep k-groups of every K tile; the
 // partial accumulators are summed through LDS at the end).  With M = B*k = 1280 decode rows an output
 // of 1280 x 512 is only 640 MFMA tiles for 1024 SIMDs; splitting K inside 32x32 workgroups turns that
 // into 2560 wave-sized tasks without any cross-workgroup reduction.
-template <int BM, int BN, int WM, int WN, int WK>
+template <int BM, int BN, int WM, int WN, int WK, int BK>
 struct TileConfig {
+    static constexpr int LDT = BK + 4;             // padded LDS row stride (floats)
     static constexpr int kThreads = 256;
     static constexpr int kWaveM = BM / WM;         // rows per wave
     static constexpr int kWaveN = BN / WN;         // cols per wave
@@ -58,9 +61,12 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return base + (bid >> 3);
 }
 
-template <int BM, int BN, int WM, int WN, int WK>
+template <int BM, int BN, int WM, int WN, int WK, int BK>
 __global__ __launch_bounds__(256) void gemm_f32_mfma(GemmArgs p, int tiles_m, int tiles_n_per_seg) {
-    using Cfg = TileConfig<BM, BN, WM, WN, WK>;
+    using Cfg = TileConfig<BM, BN, WM, WN, WK, BK>;
+    constexpr int LDT = Cfg::LDT;
+    constexpr int kVecPerRow = BK / 4;               // float4 per tile row
+    constexpr int kRowsPerPass = 256 / kVecPerRow;   // tile rows covered by one pass of the 256 loader threads
     extern __shared__ __attribute__((aligned(16))) float lds[];
 
     const int tid = threadIdx.x;
@@ -93,7 +99,7 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma(GemmArgs p, int tiles_m, in
     const bool k_tail = (K % BK) != 0 || (p.K1 % BK) != 0;   // uniform; false for every real shape
     bool a_ok = true, w_ok = true;
     auto load_tile = [&](int kt) {
-        const int kq = tid & 7;
+        const int kq = tid % kVecPerRow;
         const int k0 = kt * BK;
         const bool second = k0 >= p.K1;                       // uniform
         const float* __restrict__ Ab = second ? p.A2 : p.A1;
@@ -107,13 +113,13 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma(GemmArgs p, int tiles_m, in
         const int kwc = min(kw, K - 4);
 #pragma unroll
         for (int i = 0; i < Cfg::kLoadA; ++i) {
-            const int row = (tid >> 3) + i * 32;
+            const int row = tid / kVecPerRow + i * kRowsPerPass;
             const int gm = min(m0 + row, p.M - 1);
             stage_a[i] = *reinterpret_cast<const f32x4*>(Ab + (size_t)gm * lda + kac);
         }
 #pragma unroll
         for (int i = 0; i < Cfg::kLoadB; ++i) {
-            const int row = (tid >> 3) + i * 32;
+            const int row = tid / kVecPerRow + i * kRowsPerPass;
             const int gn = min(n0 + row, p.seg_n - 1);
             stage_b[i] = *reinterpret_cast<const f32x4*>(W + (size_t)gn * K + kwc);
         }
@@ -121,7 +127,7 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma(GemmArgs p, int tiles_m, in
     // The loaded registers are first touched here, after the MFMA block of the previous tile, so the
     // global-load latency hides under the matrix work (issue early / write late).
     auto store_tile = [&](int buf) {
-        const int kq = tid & 7;
+        const int kq = tid % kVecPerRow;
         if (k_tail) {
 #pragma unroll
             for (int i = 0; i < Cfg::kLoadA; ++i)
@@ -132,12 +138,12 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma(GemmArgs p, int tiles_m, in
         }
 #pragma unroll
         for (int i = 0; i < Cfg::kLoadA; ++i) {
-            const int row = (tid >> 3) + i * 32;
+            const int row = tid / kVecPerRow + i * kRowsPerPass;
             *reinterpret_cast<f32x4*>(lds + buf * kBufFloats + row * LDT + kq * 4) = stage_a[i];
         }
 #pragma unroll
         for (int i = 0; i < Cfg::kLoadB; ++i) {
-            const int row = (tid >> 3) + i * 32;
+            const int row = tid / kVecPerRow + i * kRowsPerPass;
             *reinterpret_cast<f32x4*>(lds + buf * kBufFloats + (BM + row) * LDT + kq * 4) = stage_b[i];
         }
     };
@@ -257,37 +263,53 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma(GemmArgs p, int tiles_m, in
     }
 }
 
-template <int BM, int BN, int WM, int WN, int WK>
+template <int BM, int BN, int WM, int WN, int WK, int BK>
 int launch_config(const GemmArgs& a, hipStream_t stream) {
-    using Cfg = TileConfig<BM, BN, WM, WN, WK>;
+    using Cfg = TileConfig<BM, BN, WM, WN, WK, BK>;
     const int tiles_m = (a.M + BM - 1) / BM;
     const int tiles_n = (a.seg_n + BN - 1) / BN;
     const int grid = tiles_m * tiles_n * a.nseg;
     const size_t lds_bytes = sizeof(float) * Cfg::kLdsFloats;
     static bool attr_set = false;   // raise the dynamic-LDS cap once per process (idempotent)
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f32_mfma<BM, BN, WM, WN, WK>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f32_mfma<BM, BN, WM, WN, WK, BK>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_f32_mfma<BM, BN, WM, WN, WK>), dim3(grid), dim3(256), lds_bytes, stream, a, tiles_m, tiles_n);
+    hipLaunchKernelGGL((gemm_f32_mfma<BM, BN, WM, WN, WK, BK>), dim3(grid), dim3(256), lds_bytes, stream, a, tiles_m, tiles_n);
     OVC_RETURN_IF_LAUNCH_FAILED();
     return OVC_OK;
 }
 
-struct TilingInfo { int bm, bn, wk; };
+struct TilingInfo { int bm, bn, wk, bk; };
 constexpr TilingInfo kTilings[] = {
-    {128, 128, 1},   // 0
-    {64, 128, 1},    // 1
-    {128, 64, 1},    // 2
-    {64, 64, 1},     // 3
-    {32, 64, 2},     // 4
-    {64, 32, 2},     // 5
-    {32, 32, 4},     // 6
+    {128, 128, 1, 32},   // 0
+    {64, 128, 1, 32},    // 1
+    {128, 64, 1, 32},    // 2
+    {64, 64, 1, 32},     // 3
+    {32, 64, 2, 32},     // 4
+    {64, 32, 2, 32},     // 5
+    {32, 32, 4, 32},     // 6
+    {64, 64, 1, 64},     // 7   deeper K tiles: twice the MFMA work per barrier / load round trip
+    {32, 64, 2, 64},     // 8
+    {64, 32, 2, 64},     // 9
+    {32, 32, 4, 64},     // 10
+    {64, 128, 1, 64},    // 11
 };
 constexpr int kNumTilings = sizeof(kTilings) / sizeof(kTilings[0]);
 
 int g_forced_tiling = -1;   // tuning hook (ovc_debug_force_gemm_tiling); -1 = automatic
+
+// Shapes measured by ovc_gemm_tune: (M, seg_n, nseg, K) -> fastest tiling on this device.
+struct TunedShape { int M, seg_n, nseg, K, tiling; };
+std::vector<TunedShape> g_tuned;
+
+int tuned_lookup(const GemmArgs& a) {
+    const int K = a.K1 + a.K2;
+    for (const TunedShape& t : g_tuned)
+        if (t.M == a.M && t.seg_n == a.seg_n && t.nseg == a.nseg && t.K == K) return t.tiling;
+    return -1;
+}
 
 // Predicted time of a tiling in MFMA-issue units (one unit = one v_mfma_f32_32x32x2_f32 slot of a
 // SIMD): every SIMD of a CU executes the waves of the workgroups resident on that CU, so the critical
@@ -299,7 +321,7 @@ double tiling_cost(const GemmArgs& a, const TilingInfo& t) {
     const long wgs = (long)((a.M + t.bm - 1) / t.bm) * ((a.seg_n + t.bn - 1) / t.bn) * a.nseg;
     const double per_cu = (double)((wgs + 255) / 256);                       // workgroups on the busiest CU
     const double mfma_per_wave = (double)(t.bm / 32) * (t.bn / 32) * (K / 2.0) / 4.0;
-    const double overhead = 48.0;                                            // ~3k cycles of non-MFMA time per workgroup
+    const double overhead = 48.0 + (t.bk == 64 ? 1e9 : 0.0);                 // BK=64 tilings: only when forced (tuning)
     const double bytes_per_flop = 2.0 * (t.bm + t.bn) / (double)(t.bm * t.bn);   // operand floats per MAC
     const double bw_penalty = 1.0 + 4.0 * bytes_per_flop;                    // 128x128: 1.06, 32x32: 1.5
     return per_cu * (mfma_per_wave * bw_penalty + overhead);
@@ -313,38 +335,109 @@ extern "C" int ovc_debug_force_gemm_tiling(int tiling) {
     return OVC_OK;
 }
 
+const char* ovc_gemm_tiling_name(int tiling) {
+    static const char* names[] = {"gemm_f32_mfma<128, 128, 2, 2, 1, 32>", "gemm_f32_mfma<64, 128, 2, 2, 1, 32>",
+                                  "gemm_f32_mfma<128, 64, 2, 2, 1, 32>", "gemm_f32_mfma<64, 64, 2, 2, 1, 32>",
+                                  "gemm_f32_mfma<32, 64, 1, 2, 2, 32>", "gemm_f32_mfma<64, 32, 2, 1, 2, 32>",
+                                  "gemm_f32_mfma<32, 32, 1, 1, 4, 32>", "gemm_f32_mfma<64, 64, 2, 2, 1, 64>",
+                                  "gemm_f32_mfma<32, 64, 1, 2, 2, 64>", "gemm_f32_mfma<64, 32, 2, 1, 2, 64>",
+                                  "gemm_f32_mfma<32, 32, 1, 1, 4, 64>", "gemm_f32_mfma<64, 128, 2, 2, 1, 64>"};
+    return tiling >= 0 && tiling < kNumTilings ? names[tiling] : "";
+}
+
+int ovc_gemm_pick_tiling(const GemmArgs& a) {
+    if (g_forced_tiling >= 0 && (a.nseg == 1 || a.seg_n % kTilings[g_forced_tiling].bn == 0)) return g_forced_tiling;
+    const int tuned = tuned_lookup(a);
+    if (tuned >= 0) return tuned;
+    double best = 1e300;
+    int pick = -1;
+    for (int i = 0; i < kNumTilings; ++i) {
+        if (a.nseg > 1 && a.seg_n % kTilings[i].bn) continue;
+        const double c = tiling_cost(a, kTilings[i]);
+        if (c < best) { best = c; pick = i; }
+    }
+    return pick;
+}
+
 int ovc_gemm_launch(const GemmArgs& a, hipStream_t stream) {
     const int K = a.K1 + a.K2;
     if (a.M <= 0 || a.seg_n <= 0 || a.nseg <= 0 || a.nseg > OVC_MAX_SEGMENTS || K <= 0) return OVC_EINVAL;
     if ((a.K1 & 3) || (a.K2 & 3) || (a.lda1 & 3) || (a.K2 && (a.lda2 & 3))) return OVC_EINVAL;
     if (!ovc_aligned16(a.A1) || (a.K2 && !ovc_aligned16(a.A2))) return OVC_EINVAL;
     if (a.R && a.nseg != 1) return OVC_EINVAL;
-    if (a.K2 > 0 && (a.K1 % BK)) return OVC_EINVAL;      // the A1|A2 seam must fall on a K-tile boundary
+    if (a.K2 > 0 && (a.K1 % 64)) return OVC_EINVAL;      // the A1|A2 seam must fall on a K-tile boundary
     for (int s = 0; s < a.nseg; ++s)
         if (!a.seg[s].W || !a.seg[s].C || !ovc_aligned16(a.seg[s].W)) return OVC_EINVAL;
     if (a.nseg > 1 && a.seg_n % 64) return OVC_EINVAL;   // a tile may not straddle two segments
 
-    int pick = -1;
-    if (g_forced_tiling >= 0 && (a.nseg == 1 || a.seg_n % kTilings[g_forced_tiling].bn == 0)) {
-        pick = g_forced_tiling;
-    } else {
-        double best = 1e300;
-        for (int i = 0; i < kNumTilings; ++i) {
-            if (a.nseg > 1 && a.seg_n % kTilings[i].bn) continue;
-            const double c = tiling_cost(a, kTilings[i]);
-            if (c < best) { best = c; pick = i; }
-        }
-    }
+    const int pick = ovc_gemm_pick_tiling(a);
     switch (pick) {
-        case 0: return launch_config<128, 128, 2, 2, 1>(a, stream);
-        case 1: return launch_config<64, 128, 2, 2, 1>(a, stream);
-        case 2: return launch_config<128, 64, 2, 2, 1>(a, stream);
-        case 3: return launch_config<64, 64, 2, 2, 1>(a, stream);
-        case 4: return launch_config<32, 64, 1, 2, 2>(a, stream);
-        case 5: return launch_config<64, 32, 2, 1, 2>(a, stream);
-        case 6: return launch_config<32, 32, 1, 1, 4>(a, stream);
+        case 0: return launch_config<128, 128, 2, 2, 1, 32>(a, stream);
+        case 1: return launch_config<64, 128, 2, 2, 1, 32>(a, stream);
+        case 2: return launch_config<128, 64, 2, 2, 1, 32>(a, stream);
+        case 3: return launch_config<64, 64, 2, 2, 1, 32>(a, stream);
+        case 4: return launch_config<32, 64, 1, 2, 2, 32>(a, stream);
+        case 5: return launch_config<64, 32, 2, 1, 2, 32>(a, stream);
+        case 6: return launch_config<32, 32, 1, 1, 4, 32>(a, stream);
+        case 7: return launch_config<64, 64, 2, 2, 1, 64>(a, stream);
+        case 8: return launch_config<32, 64, 1, 2, 2, 64>(a, stream);
+        case 9: return launch_config<64, 32, 2, 1, 2, 64>(a, stream);
+        case 10: return launch_config<32, 32, 1, 1, 4, 64>(a, stream);
+        case 11: return launch_config<64, 128, 2, 2, 1, 64>(a, stream);
         default: return OVC_EINVAL;
     }
+}
+
+// Measure every tiling on one GEMM shape and remember the fastest (process-wide).  Synchronises the
+// stream: call it at set-up time, never inside a captured or latency-sensitive region.
+extern "C" int ovc_gemm_tune(int M, int seg_n, int nseg, int K, void* scratch, size_t scratch_bytes, ovc_stream stream) {
+    if (M <= 0 || seg_n <= 0 || nseg <= 0 || nseg > OVC_MAX_SEGMENTS || K <= 0 || (K & 3)) return OVC_EINVAL;
+    const size_t na = (size_t)M * K, nw = (size_t)seg_n * nseg * K, nc = (size_t)M * seg_n * nseg;
+    if (!scratch || scratch_bytes < sizeof(float) * (na + nw + nc) || !ovc_aligned16(scratch)) return OVC_EWORKSPACE;
+    if (nseg > 1 && seg_n % 64) return OVC_EINVAL;
+    float* A = reinterpret_cast<float*>(scratch);
+    float* W = A + ((na + 3) & ~(size_t)3);
+    float* C = W + ((nw + 3) & ~(size_t)3);
+    if ((size_t)(C - A) + nc > scratch_bytes / sizeof(float)) return OVC_EWORKSPACE;
+    GemmArgs a{};
+    a.A1 = A; a.lda1 = K; a.K1 = K; a.M = M; a.seg_n = seg_n; a.nseg = nseg; a.ldc = seg_n;
+    for (int s = 0; s < nseg; ++s) a.seg[s] = GemmSegment{W + (size_t)s * seg_n * K, nullptr, C + (size_t)s * M * seg_n};
+    if (tuned_lookup(a) >= 0) return OVC_OK;
+    hipStream_t st = ovc_hip_stream(stream);
+    hipEvent_t e0, e1;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return OVC_ELAUNCH;
+    const int saved = g_forced_tiling;
+    float best_ms = 1e30f;
+    int best = -1, rc = OVC_OK;
+    for (int t = 0; t < kNumTilings && rc == OVC_OK; ++t) {
+        if (nseg > 1 && seg_n % kTilings[t].bn) continue;
+        g_forced_tiling = t;
+        for (int i = 0; i < 2 && rc == OVC_OK; ++i) rc = ovc_gemm_launch(a, st);
+        (void)hipEventRecord(e0, st);
+        for (int i = 0; i < 6 && rc == OVC_OK; ++i) rc = ovc_gemm_launch(a, st);
+        (void)hipEventRecord(e1, st);
+        if (hipEventSynchronize(e1) != hipSuccess) rc = OVC_ELAUNCH;
+        float ms = 0.f;
+        if (rc == OVC_OK && hipEventElapsedTime(&ms, e0, e1) == hipSuccess && ms < best_ms) { best_ms = ms; best = t; }
+    }
+    g_forced_tiling = saved;
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    if (rc != OVC_OK) return rc;
+    if (best >= 0) g_tuned.push_back(TunedShape{M, seg_n, nseg, K, best});
+    return OVC_OK;
+}
+
+// Tuning helper: `iters` back-to-back launches of one GEMM on `stream` (no host work in between).
+extern "C" int ovc_debug_repeat_linear(const float* x, int K, const float* W, const float* bias, float* y, int M, int N,
+                                       int iters, ovc_stream stream) {
+    GemmArgs a{};
+    a.A1 = x; a.lda1 = K; a.K1 = K; a.M = M; a.seg_n = N; a.nseg = 1; a.ldc = N; a.act = 0;
+    a.seg[0] = GemmSegment{W, bias, y};
+    for (int i = 0; i < iters; ++i) {
+        const int rc = ovc_gemm_launch(a, ovc_hip_stream(stream));
+        if (rc != OVC_OK) return rc;
+    }
+    return OVC_OK;
 }
 
 extern "C" int ovc_linear(const float* x, int ldx, const float* x2, int ldx2, int K1, int K2,

@@ -47,12 +47,15 @@ def _ffn(dst, pwff):
 
 
 class CaptionEngine:
+    autotune = True      # measure GEMM tilings per shape on first use (one-off ~0.2 s, synchronises)
+
     def __init__(self, model):
         self.lib = native.load()
         self.model = model
         self._keep = []          # tensors created here whose storage the pointer table references
         self.desc = self._describe(model)
         self._workspaces = {}    # one scratch buffer per HIP stream: concurrent batches never share state
+        self._tuned = set()
         self.device = next(model.parameters()).device
         if self.device.type != "cuda":
             raise native.OvcError("the fused engine needs the model on a HIP device (got {}); "
@@ -103,6 +106,44 @@ class CaptionEngine:
         d.fc = _p(dec.fc.weight.detach())
         return d
 
+    # -- GEMM tiling selection ------------------------------------------------------------------
+    def gemm_shapes(self, B, N, k):
+        """(M, seg_n, nseg, K) of every GEMM the engine issues for batch B, N regions, beam k."""
+        d = self.desc
+        dm, hk, hv, ff, L = d.d_model, d.heads * d.d_k, d.heads * d.d_v, d.d_ff, d.n_dec
+        shapes = set()
+        bn = B * N
+        shapes.add((bn, dm, 1, d.d_feat))
+        shapes.update({(bn, hk, 3, dm), (bn, dm, 1, hv), (bn, ff, 1, dm), (bn, dm, 1, ff)})
+        for l0 in range(0, L, 4):
+            shapes.add((bn, hk, 2 * min(4, L - l0), dm))
+        for rows in {B, B * k}:
+            shapes.update({(rows, hk, 3, dm), (rows, dm, 1, hv), (rows, hk, 1, dm), (rows, ff, 1, dm),
+                           (rows, dm, 1, ff), (rows, d.vocab, 1, dm)})
+            if d.dec_kind == native.DEC_MESHED:
+                shapes.add((rows, dm, 1, 2 * dm))
+        for rows, aoa in ((bn, self.model.encoder.layers[0].mhatt.use_aoa),
+                          (B, self.model.decoder.layers[0].self_attn.use_aoa),
+                          (B * k, self.model.decoder.layers[0].self_attn.use_aoa)):
+            if aoa:
+                shapes.add((rows, dm, 2 if dm % 64 == 0 else 1, 2 * dm))
+        return sorted(shapes)
+
+    def tune(self, B, N, k):
+        """Time every GEMM tiling on the engine's shapes once (synchronises; ~0.2 s) and let the
+        library remember the fastest per shape."""
+        key = (B, N, k)
+        if key in self._tuned:
+            return
+        shapes = self.gemm_shapes(B, N, k)
+        need = max(4 * (m * kk + sn * ns * kk + m * sn * ns) + 256 for m, sn, ns, kk in shapes)
+        scratch = torch.empty(need // 4 + 16, dtype=torch.float32, device=self.device).normal_()
+        for m, sn, ns, kk in shapes:
+            check(self.lib.ovc_gemm_tune(m, sn, ns, kk, scratch.data_ptr(), scratch.numel() * 4, native.stream_handle()),
+                  "ovc_gemm_tune{}".format((m, sn, ns, kk)))
+        torch.cuda.current_stream().synchronize()
+        self._tuned.add(key)
+
     # -- workspace ----------------------------------------------------------------------------
     def _get_workspace(self, B, N, k, return_probs):
         need = self.lib.ovc_workspace_bytes(ctypes.byref(self.desc), B, N, k, 1 if return_probs else 0)
@@ -145,6 +186,8 @@ class CaptionEngine:
             raise native.OvcError("batch_size={} but features hold {} images".format(batch_size, B))
         d = self.desc
         T, V = d.max_len, d.vocab
+        if self.autotune:
+            self.tune(B, N, beam_size)
         ws, need = self._get_workspace(B, N, beam_size, return_probs)
         ids = torch.empty(B, out_size, T, dtype=torch.int64, device=self.device)
         logp = torch.empty(B, out_size, T, dtype=torch.float32, device=self.device)
