@@ -22,6 +22,8 @@ Fixture families:
   G3  tiny configuration with a sharpened vocabulary projection that forces <eos> and <pad>
   G4  operator-level geometry cross-attention with nq != nk and a per-query mask (DLCT form)
   G5  box relation embedding for both ``trignometric_embedding`` values
+  G6  ids -> caption strings through the reference's ``Vocab.decode_caption`` + duplicate collapse
+  G7  a checkpoint written by the reference (its own initialisation) with its beam-search output
 """
 import argparse
 import os
@@ -271,6 +273,44 @@ def g5_box_relation(ref, out_dir):
     print("wrote g5_box_relation.npz")
 
 
+def g6_decode_caption(ref, out_dir):
+    """ids -> words (stop at <eos>, drop specials) and the trainer's duplicate-word collapse
+    (data_utils/vocab.py:104-122, trainers/vi_trainer.py:247-252)."""
+    import itertools
+    import json
+    from data_utils.vocab import Vocab
+    vocab = object.__new__(Vocab)          # the constructor needs the dataset json; only these fields are read
+    vocab.itos = ["<pad>", "<bos>", "<eos>", "<unk>"] + ["w%02d" % i for i in range(49)]
+    vocab.specials = vocab.itos[:4]
+    vocab.eos_idx = 2
+    forced = np.load(os.path.join(out_dir, "g3_forced_eos_pad.npz"))["ids"].reshape(-1, 8)
+    extra = np.array([[4, 4, 4, 5, 5, 2, 9, 9], [1, 3, 7, 7, 0, 7, 2, 2], [2, 0, 0, 0, 0, 0, 0, 0], [6, 7, 8, 9, 10, 11, 12, 13]])
+    ids = torch.from_numpy(np.concatenate([forced, extra]))
+    joined = vocab.decode_caption(ids, join_words=True)
+    split = vocab.decode_caption(ids, join_words=False)
+    collapsed = [" ".join(k for k, _ in itertools.groupby(words)) for words in split]
+    with open(os.path.join(out_dir, "g6_decode_caption.json"), "w") as f:
+        json.dump({"itos": vocab.itos, "ids": ids.tolist(), "joined": joined, "split": split, "collapsed": collapsed}, f)
+    print("wrote g6_decode_caption.json (%d captions)" % len(joined))
+
+
+def g7_reference_checkpoint(ref, out_dir):
+    """A state_dict exactly as the reference's own constructors and torch.save produce it
+    (trainers/base_trainer.py:138-153 stores it under 'state_dict')."""
+    s = TINY_SHAPE
+    for variant in ("standard_transformer", "meshed_memory_transformer"):
+        cfg = model_config(variant, **TINY)
+        cfg.DEVICE = "cpu"
+        torch.manual_seed(99)
+        model = ref["build_model"](cfg, SyntheticVocab(s["V"], s["T"])).eval()
+        items = make_inputs(ref, s["B"], s["N"], TINY["d_feature"], seed=3, ragged=True, boxes=False)
+        with torch.no_grad():
+            ids, logp = model.beam_search(items, batch_size=s["B"], beam_size=s["k"], out_size=1)
+        torch.save({"state_dict": model.state_dict(), "epoch": 3, "beam_ids": ids, "beam_logp": logp},
+                   os.path.join(out_dir, "g7_reference_checkpoint_%s.pth" % variant))
+        print("wrote g7_reference_checkpoint_%s.pth (%d tensors)" % (variant, len(model.state_dict())))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reference", default="/root/reference")
@@ -292,6 +332,10 @@ def main():
         g4_dlct_operator(ref, HERE)
     if on("g5"):
         g5_box_relation(ref, HERE)
+    if on("g6"):
+        g6_decode_caption(ref, HERE)
+    if on("g7"):
+        g7_reference_checkpoint(ref, HERE)
     if on("g2"):
         for v in VARIANTS:
             g2_full(ref, HERE, v)

@@ -172,3 +172,43 @@ def test_oracle_agreement_on_ragged_inputs():
     assert_ids_match_where_decided(ids.cpu().numpy(), want_ids.numpy(), gaps, inner, MARGIN, "ragged")
     same = (ids.cpu().numpy() == want_ids.numpy()).all(axis=1)
     _logp_close(logp.cpu().numpy()[same], want_logp.numpy()[same], "ragged log-probs")
+
+
+def test_reference_checkpoint_runs_on_the_engine():
+    """G7: weights initialised and saved by the reference itself -> same beam-search output."""
+    import os
+    from helpers import GOLDEN, TINY
+    from openviic_amd.builders import build_model
+    from openviic_amd.checkpoint import load_reference_checkpoint
+    from openviic_amd.config import model_config
+    from openviic_amd.utils.synthetic import SyntheticVocab, synthetic_features
+    for variant in ("standard_transformer", "meshed_memory_transformer"):
+        path = os.path.join(GOLDEN, "g7_reference_checkpoint_%s.pth" % variant)
+        ckpt = torch.load(path, map_location="cpu", weights_only=True)
+        vocab = SyntheticVocab(TINY_SHAPE["V"], TINY_SHAPE["T"])
+        model = build_model(model_config(variant, device="cuda", **TINY), vocab).eval()
+        load_reference_checkpoint(model, path)
+        feats = synthetic_features(TINY_SHAPE["B"], TINY_SHAPE["N"], TINY["d_feature"], seed=3, ragged=True)
+        with torch.no_grad():
+            ids, logp = model.beam_search(batch(feats), batch_size=TINY_SHAPE["B"], beam_size=TINY_SHAPE["k"])
+        np.testing.assert_array_equal(ids.cpu().numpy(), ckpt["beam_ids"].numpy())
+        _logp_close(logp.cpu().numpy(), ckpt["beam_logp"].numpy(), "reference checkpoint " + variant)
+
+
+@pytest.mark.parametrize("variant", ["meshed_memory_transformer", "object_relation_transformer", "attention_on_attention"])
+def test_batch_256_properties_other_architectures(variant):
+    """BASELINE configs 3 and 4 (and AoA) at the full batch: halves == whole, run-to-run identical,
+    first 16 images == the B=16 reference golden (ORT draws boxes per batch, so it checks B=16 separately)."""
+    g = golden("g2_full_%s.npz" % variant)
+    cfg, vocab, sd, feats, boxes = full_case(variant, 256)
+    model = device_model(cfg, vocab, sd)
+    with torch.no_grad():
+        ids, logp = model.beam_search(batch(feats, boxes), batch_size=256, beam_size=5)
+        again, _ = model.beam_search(batch(feats, boxes), batch_size=256, beam_size=5)
+        lo, _ = model.beam_search(batch(feats[:128], None if boxes is None else boxes[:128]), batch_size=128, beam_size=5)
+        hi, _ = model.beam_search(batch(feats[128:], None if boxes is None else boxes[128:]), batch_size=128, beam_size=5)
+    assert torch.equal(ids, again) and torch.equal(ids, torch.cat([lo, hi]))
+    assert torch.isfinite(logp).all() and ids.min() >= 0 and ids.max() < FULL["V"]
+    if boxes is None:
+        same = (ids[:16].cpu().numpy() == g["B16_k5_ids"]).all(axis=1)
+        assert same.mean() >= 0.9
