@@ -183,8 +183,9 @@ int ovc_beam_search(const ovc_model* m, const float* features, const float* boxe
                     int64_t* ids_out, float* logp_out, float* all_logp_out, ovc_stream stream);
 
 /* Optional device timing of the engine's GEMM launches (bench.py's roofline leg).  While enabled,
- * every GEMM launch is bracketed by hipEvents on its launch stream; the bracket's own overhead is
- * calibrated with empty event pairs and subtracted.  ovc_profile_read synchronises the events and
+ * every GEMM launch is bracketed by hipEvents on its launch stream.  The bracket includes the
+ * marker / dispatch latency (about 3 us per launch against rocprofv3's kernel duration); nothing
+ * is subtracted, ovc_profile_overhead_ms reports the duration of an empty bracket for reference.  ovc_profile_read synchronises the events and
  * returns launches, total milliseconds and total algorithmic FLOPs (2*M*N*K), either per GEMM
  * class (kind 0: 0 feature projection, 1 encoder, 2 decoder projections/FFN, 3 vocabulary) or per
  * kernel instance (kind 1: tiling index, name from ovc_profile_kernel_name).  Enabling resets. */
@@ -200,6 +201,10 @@ const char* ovc_profile_kernel_name(int tiling);   /* "" past the last tiling */
  * (contents are used as operands).  SYNCHRONISES the stream -- set-up time only. */
 int ovc_gemm_tune(int M, int seg_n, int nseg, int K, void* scratch, size_t scratch_bytes,
                   ovc_stream stream);
+
+/* Read / preset the remembered tiling of a shape (-1 = not tuned): lets a host persist tuning results. */
+int ovc_gemm_tuned_get(int M, int seg_n, int nseg, int K);
+int ovc_gemm_tuned_set(int M, int seg_n, int nseg, int K, int tiling);
 
 /* Tuning hook (tools/gemm_bench.py): force GEMM tiling 0..6 (see csrc/gemm.hip) for every
  * following ovc_linear / engine GEMM in this process; -1 restores the automatic choice. */

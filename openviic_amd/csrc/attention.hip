@@ -202,6 +202,9 @@ extern "C" int ovc_attention(const float* q, const float* k, const float* v, int
 //   phase 3  out = P V: thread = (float4 column, key group); groups are combined through LDS
 constexpr int kSelfMaxHeads = 32;
 
+// CH = float4-per-lane instructions per key row (h*dk / 256 rounded up): compile-time so that the loads of
+// several keys can be issued back to back with clamped (always valid) addresses and no branches.
+template <int CH>
 __global__ __launch_bounds__(256) void decode_self_attention_kernel(DecodeSelfArgs p) {
     __shared__ int slots[64];
     __shared__ uint8_t pads[64];
@@ -210,36 +213,47 @@ __global__ __launch_bounds__(256) void decode_self_attention_kernel(DecodeSelfAr
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = blockIdx.x, t = p.t;
     const int hk = p.h * p.dk;                       // == h * dv (checked on the host)
-    const int chunks = (hk + 255) >> 8;              // float4-per-lane instructions per key row
 
     if (tid <= t) {
         const int slot = tid == t ? r : p.anc[(size_t)r * p.anc_ld + tid];
         slots[tid] = slot;
         pads[tid] = p.padflag[(size_t)tid * p.pad_ld + slot];
     }
-    f32x4 q4[4];
+    int ecol[CH];
+    bool evalid[CH];
+    f32x4 q4[CH];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
+    for (int c = 0; c < CH; ++c) {
         const int e = c * 256 + lane * 4;
-        q4[c] = (c < chunks && e < hk) ? *reinterpret_cast<const f32x4*>(p.q + (size_t)r * p.ldq + e) : f32x4{0.f, 0.f, 0.f, 0.f};
+        evalid[c] = e < hk;
+        ecol[c] = min(e, hk - 4);
+        q4[c] = *reinterpret_cast<const f32x4*>(p.q + (size_t)r * p.ldq + ecol[c]);
+        if (!evalid[c]) q4[c] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     __syncthreads();
 
     const int group = p.dk >> 2;                     // lanes per head: a power of two <= 16
     const float scale_div = sqrtf((float)p.dk);
-    for (int j = wave; j <= t; j += 4) {
-        const float* krow = p.kcache + (size_t)j * p.pos_stride + (size_t)slots[j] * p.ldkv;
+    const int niter = (t - wave + 4) >> 2;           // keys wave, wave+4, ... <= t
+    for (int i0 = 0; i0 < niter; i0 += 4) {
+        f32x4 k4[4][CH];
+        int jj[4];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            if (c < chunks) {
-                const int e = c * 256 + lane * 4;
-                float part = 0.f;
-                if (e < hk) {
-                    const f32x4 k4 = *reinterpret_cast<const f32x4*>(krow + e);
-                    part = (q4[c][0] * k4[0] + q4[c][1] * k4[1]) + (q4[c][2] * k4[2] + q4[c][3] * k4[3]);
-                }
+        for (int u = 0; u < 4; ++u) {                // four keys in flight per wave
+            jj[u] = min(wave + 4 * (i0 + u), t);
+            const float* krow = p.kcache + (size_t)jj[u] * p.pos_stride + (size_t)slots[jj[u]] * p.ldkv;
+#pragma unroll
+            for (int c = 0; c < CH; ++c) k4[u][c] = *reinterpret_cast<const f32x4*>(krow + ecol[c]);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const bool live = i0 + u < niter;
+#pragma unroll
+            for (int c = 0; c < CH; ++c) {
+                float part = (q4[c][0] * k4[u][c][0] + q4[c][1] * k4[u][c][1]) + (q4[c][2] * k4[u][c][2] + q4[c][3] * k4[u][c][3]);
                 for (int off = 1; off < group; off <<= 1) part += __shfl_xor(part, off, 64);
-                if (e < hk && (lane & (group - 1)) == 0) sc[e / p.dk][j] = pads[j] ? -INFINITY : part / scale_div;
+                if (live && evalid[c] && (lane & (group - 1)) == 0)
+                    sc[(c * 256 + lane * 4) / p.dk][jj[u]] = pads[jj[u]] ? -INFINITY : part / scale_div;
             }
         }
     }
@@ -257,15 +271,22 @@ __global__ __launch_bounds__(256) void decode_self_attention_kernel(DecodeSelfAr
     const int cols = hk >> 2;                        // float4 columns of the output row (<= 256)
     const int groups = 256 / cols;                   // key groups working in parallel
     const int col = tid % cols, g = tid / cols;
+    const int hd = (col * 4) / p.dv;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    if (g < groups) {
-        const int hd = (col * 4) / p.dv;
-        for (int j = g; j <= t; j += groups) {
-            const f32x4 v4 = *reinterpret_cast<const f32x4*>(p.vcache + (size_t)j * p.pos_stride + (size_t)slots[j] * p.ldkv + col * 4);
-            acc += v4 * sc[hd][j];
+    const int nkeys = (t - g + groups) / groups;     // keys g, g+groups, ... <= t  (0 when g > t)
+    for (int i0 = 0; i0 < nkeys; i0 += 4) {
+        f32x4 v4[4];
+        int jj[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            jj[u] = min(g + groups * (i0 + u), t);
+            v4[u] = *reinterpret_cast<const f32x4*>(p.vcache + (size_t)jj[u] * p.pos_stride + (size_t)slots[jj[u]] * p.ldkv + col * 4);
         }
-        if (g > 0) *reinterpret_cast<f32x4*>(red + (size_t)tid * 4) = acc;
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (i0 + u < nkeys) acc += v4[u] * sc[hd][jj[u]];
     }
+    if (g > 0) *reinterpret_cast<f32x4*>(red + (size_t)tid * 4) = acc;
     __syncthreads();
     if (g == 0) {
         for (int gg = 1; gg < groups; ++gg) acc += *reinterpret_cast<const f32x4*>(red + (size_t)(gg * cols + col) * 4);
@@ -278,12 +299,145 @@ int ovc_decode_self_attention(const DecodeSelfArgs& p, int rows, hipStream_t str
     if (p.t < 0 || p.t >= 64 || p.h <= 0 || p.h > kSelfMaxHeads) return OVC_EINVAL;
     if (p.dk != p.dv || (p.dk & (p.dk - 1)) || p.dk < 4 || p.dk > 64) return OVC_EINVAL;   // dk in {4,8,16,32,64}
     if (hk > 1024 || 256 % (hk >> 2)) return OVC_EINVAL;                                   // h*dk in {64,128,256,512,1024}
-    hipLaunchKernelGGL(decode_self_attention_kernel, dim3(rows), dim3(256), 0, stream, p);
+    if (hk <= 256) hipLaunchKernelGGL(decode_self_attention_kernel<1>, dim3(rows), dim3(256), 0, stream, p);
+    else if (hk <= 512) hipLaunchKernelGGL(decode_self_attention_kernel<2>, dim3(rows), dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL(decode_self_attention_kernel<4>, dim3(rows), dim3(256), 0, stream, p);
     OVC_RETURN_IF_LAUNCH_FAILED();
     return OVC_OK;
 }
 
-__global__ __launch_bounds__(256) void decode_cross_attention_kernel(DecodeCrossArgs p) {
+// Decode cross-attention: the k beams of an image share the image's projected encoder K/V.
+//
+// decode_cross_attention_mfma_kernel -- one wave per (image, head, level), no LDS, both contractions on
+// the matrix cores (v_mfma_f32_16x16x4_f32) with the beams as the 16-wide N dimension:
+//   S^T[key][beam] = K Q^T : A = K rows (16 keys per tile), B = Q^T.  Lane (r = lane & 15, kq = lane >> 4)
+//       loads float4 K[key r][16 S + 4 kq ..] / Q[beam r][16 S + 4 kq ..] and feeds element e to MFMA
+//       (S, e); both operands use the same d <-> (S, kq, e) assignment, so every d is summed once.
+//   softmax over keys: the accumulator has the beam on the lane (col = lane & 15) and the keys on
+//       registers (row = 4 kq + reg): reduce over registers, then __shfl_xor 16 / 32 across the four kq lanes.
+//   O^T[dv][beam] = V^T P^T : the probabilities stay in the accumulator registers and are used directly as
+//       the B operand (lane (beam, kq), register reg  <->  key 16 T + 4 kq + reg); A = V^T is loaded as
+//       float4 V[key][4 r ..] (a fully coalesced 256-byte head slice per key) and element e' feeds MFMA e',
+//       whose output row r is dv = 4 r + e'.  Four MFMA results give each lane float4s of consecutive dv.
+// K and V are read from HBM exactly once with 16-byte loads; the kernel is bound by that stream
+// (52 MB per layer-step at B = 256).
+// NT = key tiles (16 keys each), SB = d_k / 16: compile-time so that every load below is unconditional
+// (hipcc branches around a guarded load and waits vmcnt(0) after it, serialising the whole K/V stream).
+template <int NT, int SB>
+__global__ __launch_bounds__(256) void decode_cross_attention_mfma_kernel(DecodeCrossArgs p) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = blockIdx.x, hd = min((int)blockIdx.y * 4 + wave, p.heads - 1), lvl = blockIdx.z;
+    const bool live = (int)blockIdx.y * 4 + wave < p.heads;      // surplus waves redo the last head, store nothing
+    const int N = p.n, W = p.width;
+    const int r = lane & 15, kq = lane >> 4;
+    const float* kg = p.kx + (size_t)lvl * p.level_stride + (size_t)b * N * p.ldkv + hd * p.dk;
+    const float* vg = p.vx + (size_t)lvl * p.level_stride + (size_t)b * N * p.ldkv + hd * p.dv;
+    const float* qg = p.q + (size_t)(b * W + min(r, W - 1)) * p.ldq + hd * p.dk;
+
+    // ---- all loads of the score phase, back to back -------------------------------------------------
+    f32x4 qf[SB], kf[NT][SB];
+#pragma unroll
+    for (int S = 0; S < SB; ++S) qf[S] = *reinterpret_cast<const f32x4*>(qg + 16 * S + 4 * kq);
+#pragma unroll
+    for (int T = 0; T < NT; ++T) {
+        const float* krow = kg + (size_t)min(16 * T + r, N - 1) * p.ldkv + 4 * kq;
+#pragma unroll
+        for (int S = 0; S < SB; ++S) kf[T][S] = *reinterpret_cast<const f32x4*>(krow + 16 * S);
+    }
+    // key mask bytes of this lane's keys (16 T + 4 kq + g); a dummy all-zero row when there is no mask
+    uint8_t mk[NT][4];
+#pragma unroll
+    for (int T = 0; T < NT; ++T)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) mk[T][g] = 0;
+    if (p.encmask) {                                   // uniform: one branch around all the byte loads
+        const uint8_t* mrow = p.encmask + (size_t)b * N;
+#pragma unroll
+        for (int T = 0; T < NT; ++T)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) mk[T][g] = mrow[min(16 * T + 4 * kq + g, N - 1)];
+    }
+    if (r >= W) {
+#pragma unroll
+        for (int S = 0; S < SB; ++S) qf[S] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+
+    f32x4 st[NT];
+#pragma unroll
+    for (int T = 0; T < NT; ++T) {
+        st[T] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int S = 0; S < SB; ++S)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) st[T] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[T][S][e], qf[S][e], st[T], 0, 0, 0);
+    }
+
+    // ---- V loads are issued before the softmax arithmetic so that they are in flight meanwhile ------------------
+    const int vc = 4 * min(r, (p.dv >> 2) - 1);
+    f32x4 vf[NT][4];
+#pragma unroll
+    for (int T = 0; T < NT; ++T)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            vf[T][g] = *reinterpret_cast<const f32x4*>(vg + (size_t)min(16 * T + 4 * kq + g, N - 1) * p.ldkv + vc);
+
+    // scale, mask, softmax over the keys of this lane's beam column
+    const float scale_div = sqrtf((float)p.dk);
+    float mx = -INFINITY;
+#pragma unroll
+    for (int T = 0; T < NT; ++T) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int key = 16 * T + 4 * kq + g;
+            float s = st[T][g] / scale_div;
+            if (key >= N || mk[T][g]) s = -INFINITY;
+            st[T][g] = s;
+            mx = fmaxf(mx, s);
+        }
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int T = 0; T < NT; ++T)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float e = expf(st[T][g] - mx);
+            st[T][g] = e;
+            sum += e;
+        }
+    sum += __shfl_xor(sum, 16, 64);
+    sum += __shfl_xor(sum, 32, 64);
+#pragma unroll
+    for (int T = 0; T < NT; ++T)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) st[T][g] = st[T][g] / sum;
+
+    // O^T = V^T P^T (columns of V beyond d_v contribute to output rows that are never stored)
+    f32x4 acc[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[e] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int T = 0; T < NT; ++T)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[e] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[T][g][e], st[T][g], acc[e], 0, 0, 0);
+
+    // acc[e][g] is O[beam = column][dv = 4 (4 kq + g) + e] where row 4 kq + g of the MFMA is the V column
+    // group loaded by lane r' = 4 kq + g: four consecutive dv per (lane, g)
+    if (live && r < W) {
+        float* orow = p.out + (size_t)lvl * p.out_level_stride + (size_t)(b * W + r) * p.ldo + hd * p.dv;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int dvb = 16 * kq + 4 * g;
+            if (dvb < p.dv) *reinterpret_cast<f32x4*>(orow + dvb) = f32x4{acc[0][g], acc[1][g], acc[2][g], acc[3][g]};
+        }
+    }
+}
+
+// Fallback for head sizes that are not multiples of 16: K/V of one (image, head) staged in LDS, VALU dots.
+__global__ __launch_bounds__(256) void decode_cross_attention_lds_kernel(DecodeCrossArgs p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.x, hd = blockIdx.y, lvl = blockIdx.z;
@@ -352,16 +506,27 @@ __global__ __launch_bounds__(256) void decode_cross_attention_kernel(DecodeCross
 }
 
 int ovc_decode_cross_attention(const DecodeCrossArgs& p, int B, int h, int levels, hipStream_t stream) {
-    if (p.n <= 0 || p.n > 256 || p.width <= 0 || p.width > OVC_MAX_BEAM) return OVC_EINVAL;
-    if (p.dk > 64 || p.dv > 64 || (p.dk & 3) || (p.dv & 3)) return OVC_EINVAL;
+    if (p.n <= 0 || p.n > 128 || p.width <= 0 || p.width > OVC_MAX_BEAM) return OVC_EINVAL;
+    if (p.dk > 64 || p.dv > 64 || (p.dk & 3) || (p.dv & 3) || p.heads != h) return OVC_EINVAL;
+    if (p.dk == 16 || p.dk == 32 || p.dk == 64) {
+        const dim3 grid(B, (h + 3) / 4, levels), block(256);
+        const bool small = p.n <= 64;
+#define OVC_CROSS(NT, SB) hipLaunchKernelGGL((decode_cross_attention_mfma_kernel<NT, SB>), grid, block, 0, stream, p)
+        if (p.dk == 64) { if (small) OVC_CROSS(4, 4); else OVC_CROSS(8, 4); }
+        else if (p.dk == 32) { if (small) OVC_CROSS(4, 2); else OVC_CROSS(8, 2); }
+        else { if (small) OVC_CROSS(4, 1); else OVC_CROSS(8, 1); }
+#undef OVC_CROSS
+        OVC_RETURN_IF_LAUNCH_FAILED();
+        return OVC_OK;
+    }
     const size_t lds_bytes = sizeof(float) * (2 * (size_t)p.n * kLdQK + (size_t)p.width * 64 + (size_t)p.width * p.n);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(decode_cross_attention_kernel),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(decode_cross_attention_lds_kernel),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    hipLaunchKernelGGL(decode_cross_attention_kernel, dim3(B, h, levels), dim3(256), lds_bytes, stream, p);
+    hipLaunchKernelGGL(decode_cross_attention_lds_kernel, dim3(B, h, levels), dim3(256), lds_bytes, stream, p);
     OVC_RETURN_IF_LAUNCH_FAILED();
     return OVC_OK;
 }

@@ -70,8 +70,9 @@ __device__ __forceinline__ Cand wave_topk(const float (&lv)[kMaxK], const int (&
 // registers.  Selection is threshold based: the k-th best of a wave's lane maxima bounds the k-th best
 // overall from below, so only the handful of candidates at or above that bound are collected (LDS list)
 // and ranked by one wave -- no per-candidate sorted-list maintenance on the hot path.
-template <int kPerThread, int kRows>
+template <int kPerThread, int kRows, int kVec>
 __global__ __launch_bounds__(kSelThreads) void beam_select_kernel(BeamSelectArgs p) {
+    constexpr int kElems = kPerThread * kVec;      // logits per thread per row; element (j, e) is column kVec*(tid + j*1024) + e
     __shared__ float red_max[16][kMaxK], red_sum[16][kMaxK];
     __shared__ float thr[16];
     __shared__ int count;
@@ -82,14 +83,24 @@ __global__ __launch_bounds__(kSelThreads) void beam_select_kernel(BeamSelectArgs
     const int W = p.width, V = p.V, k = p.k;
     const float* x = p.logits + (size_t)b * W * p.ld;
 
-    float xv[kRows][kPerThread];
+    float xv[kRows][kElems];
 #pragma unroll
     for (int i = 0; i < kRows; ++i) {
         if (i < W) {
 #pragma unroll
             for (int j = 0; j < kPerThread; ++j) {
-                const int c = tid + j * kSelThreads;
-                xv[i][j] = c < V ? x[(size_t)i * p.ld + c] : -INFINITY;
+                const int c0 = kVec * (tid + j * kSelThreads);
+                // unconditional loads from clamped (always valid) addresses; the tail is masked afterwards, so
+                // that all of a thread's loads are in flight together (a guarded load costs a vmcnt(0) each)
+                if (kVec == 4) {
+                    // rows are 16-byte aligned (ld % 4 == 0): one 16-byte load per lane
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(x + (size_t)i * p.ld + min(c0, (V - 1) & ~3));
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) xv[i][j * 4 + e] = c0 + e < V ? v[e] : -INFINITY;
+                } else {
+                    const float v = x[(size_t)i * p.ld + min(c0, V - 1)];
+                    xv[i][j] = c0 < V ? v : -INFINITY;
+                }
             }
         }
     }
@@ -102,7 +113,7 @@ __global__ __launch_bounds__(kSelThreads) void beam_select_kernel(BeamSelectArgs
             if (i < W) {
                 float m = -INFINITY;
 #pragma unroll
-                for (int j = 0; j < kPerThread; ++j) m = fmaxf(m, xv[i][j]);
+                for (int j = 0; j < kElems; ++j) m = fmaxf(m, xv[i][j]);
                 m = wave_max(m);
                 if (lane == 0) red_max[wave][i] = m;
             }
@@ -117,7 +128,7 @@ __global__ __launch_bounds__(kSelThreads) void beam_select_kernel(BeamSelectArgs
                 mx[i] = m;
                 float sum = 0.f;
 #pragma unroll
-                for (int j = 0; j < kPerThread; ++j) sum += expf(xv[i][j] - m);     // exp(-inf) = 0 for the tail
+                for (int j = 0; j < kElems; ++j) sum += expf(xv[i][j] - m);     // exp(-inf) = 0 for the tail
                 sum = wave_sum(sum);
                 if (lane == 0) red_sum[wave][i] = sum;
             }
@@ -147,8 +158,8 @@ __global__ __launch_bounds__(kSelThreads) void beam_select_kernel(BeamSelectArgs
             const float alive = p.alive ? p.alive[b * W + i] : 1.0f;
             float* mrow = p.masked_logp ? p.masked_logp + ((size_t)b * W + i) * V : nullptr;
 #pragma unroll
-            for (int j = 0; j < kPerThread; ++j) {
-                const int c = tid + j * kSelThreads;
+            for (int j = 0; j < kElems; ++j) {
+                const int c = kVec * (tid + (j / kVec) * kSelThreads) + (j % kVec);
                 float cand = -INFINITY;
                 if (c < V) {
                     const float lp = (xv[i][j] - mx[i]) - ls[i];
@@ -188,10 +199,11 @@ __global__ __launch_bounds__(kSelThreads) void beam_select_kernel(BeamSelectArgs
     for (int i = 0; i < kRows; ++i) {
         if (i < W) {
 #pragma unroll
-            for (int j = 0; j < kPerThread; ++j) {
-                if (tid + j * kSelThreads < V && xv[i][j] >= T) {
+            for (int j = 0; j < kElems; ++j) {
+                const int c = kVec * (tid + (j / kVec) * kSelThreads) + (j % kVec);
+                if (c < V && xv[i][j] >= T) {
                     const int pos = atomicAdd(&count, 1);
-                    if (pos < kSurvivorCap) { surv_v[pos] = xv[i][j]; surv_i[pos] = i * V + tid + j * kSelThreads; }
+                    if (pos < kSurvivorCap) { surv_v[pos] = xv[i][j]; surv_i[pos] = i * V + c; }
                 }
             }
         }
@@ -222,9 +234,9 @@ __global__ __launch_bounds__(kSelThreads) void beam_select_kernel(BeamSelectArgs
         for (int i = 0; i < kRows; ++i) {
             if (i < W) {
 #pragma unroll
-                for (int j = 0; j < kPerThread; ++j) {
-                    const int idx = i * V + tid + j * kSelThreads;
-                    if (tid + j * kSelThreads < V && better(xv[i][j], idx, lv[k - 1], li[k - 1])) list_insert(lv, li, k, xv[i][j], idx);
+                for (int j = 0; j < kElems; ++j) {
+                    const int c = kVec * (tid + (j / kVec) * kSelThreads) + (j % kVec);
+                    if (c < V && better(xv[i][j], i * V + c, lv[k - 1], li[k - 1])) list_insert(lv, li, k, xv[i][j], i * V + c);
                 }
             }
         }
@@ -328,19 +340,31 @@ __global__ __launch_bounds__(256) void beam_gather_all_kernel(const float* __res
 int ovc_beam_select_launch(const BeamSelectArgs& p, int B, hipStream_t stream) {
     if (B <= 0 || p.width <= 0 || p.width > kMaxK || p.k <= 0 || p.k > kMaxK || p.V <= 0) return OVC_EINVAL;
     if ((long)p.width * p.V < p.k || (long)p.width * p.V > 0x7fffffffL) return OVC_EINVAL;
-    const int per_thread = (p.V + kSelThreads - 1) / kSelThreads;
     const dim3 grid(B), block(kSelThreads);
-#define OVC_SELECT(PT, ROWS) hipLaunchKernelGGL((beam_select_kernel<PT, ROWS>), grid, block, 0, stream, p)
-    if (p.width == 1) {
-        if (per_thread <= 4) OVC_SELECT(4, 1); else if (per_thread <= 16) OVC_SELECT(16, 1); else return OVC_EINVAL;
-    } else if (p.width <= 5) {
-        if (per_thread <= 4) OVC_SELECT(4, 5); else if (per_thread <= 10) OVC_SELECT(10, 5);
-        else if (per_thread <= 16) OVC_SELECT(16, 5); else return OVC_EINVAL;
+    const bool vec = (p.ld & 3) == 0 && ovc_aligned16(p.logits);
+#define OVC_SELECT(PT, ROWS, VEC) hipLaunchKernelGGL((beam_select_kernel<PT, ROWS, VEC>), grid, block, 0, stream, p)
+    if (vec) {
+        const int per_thread = (p.V + 4 * kSelThreads - 1) / (4 * kSelThreads);      // 16-byte loads
+        if (p.width == 1) {
+            if (per_thread <= 1) OVC_SELECT(1, 1, 4); else if (per_thread <= 4) OVC_SELECT(4, 1, 4); else return OVC_EINVAL;
+        } else if (p.width <= 5) {
+            if (per_thread <= 1) OVC_SELECT(1, 5, 4); else if (per_thread <= 3) OVC_SELECT(3, 5, 4); else return OVC_EINVAL;
+        } else {
+            if (per_thread <= 1) OVC_SELECT(1, 8, 4); else if (per_thread <= 3) OVC_SELECT(3, 8, 4); else return OVC_EINVAL;
+        }
     } else {
-        if (per_thread <= 4) OVC_SELECT(4, 8); else if (per_thread <= 10) OVC_SELECT(10, 8); else return OVC_EINVAL;
+        const int per_thread = (p.V + kSelThreads - 1) / kSelThreads;
+        if (p.width == 1) {
+            if (per_thread <= 4) OVC_SELECT(4, 1, 1); else if (per_thread <= 16) OVC_SELECT(16, 1, 1); else return OVC_EINVAL;
+        } else if (p.width <= 5) {
+            if (per_thread <= 4) OVC_SELECT(4, 5, 1); else if (per_thread <= 10) OVC_SELECT(10, 5, 1);
+            else if (per_thread <= 16) OVC_SELECT(16, 5, 1); else return OVC_EINVAL;
+        } else {
+            if (per_thread <= 4) OVC_SELECT(4, 8, 1); else if (per_thread <= 10) OVC_SELECT(10, 8, 1); else return OVC_EINVAL;
+        }
     }
 #undef OVC_SELECT
-    // (vocabularies above 16384 words, or above 10240 with beams wider than 5, are not supported yet)
+    // (vocabularies above 12288-16384 words, or above 10240-12288 with beams wider than 5, are not supported yet)
     OVC_RETURN_IF_LAUNCH_FAILED();
     return OVC_OK;
 }

@@ -84,7 +84,7 @@ struct DecodeCrossArgs {
     int ldkv;
     const uint8_t* encmask;  // [B][N] or nullptr
     int n, width;
-    int dk, dv;
+    int heads, dk, dv;
     float* out;            // [levels][B*width][ldo]
     size_t out_level_stride;
     int ldo;

@@ -54,7 +54,7 @@ void profile_resolve() {
         (void)hipEventSynchronize(r.stop);
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, r.start, r.stop) == hipSuccess) {
-            const double net = ms > g_profile_overhead_ms ? ms - g_profile_overhead_ms : 0.0;
+            const double net = ms;      // raw bracket: includes ~3 us of marker/dispatch latency per launch
             ProfileBin& c = g_by_class[r.cls];
             c.launches += 1; c.ms += net; c.flops += r.flops;
             if (r.tiling >= 0 && r.tiling < kProfileTilings) {
@@ -139,7 +139,7 @@ Workspace carve(const ovc_model* m, void* base, int B, int N, int k, int return_
     w.kc = a.take<float>(L * T * R * hk);
     w.vc = a.take<float>(L * T * R * hv);
     w.padflag = a.take<uint8_t>(T * R);
-    w.logits = a.take<float>(R * m->vocab);
+    w.logits = a.take<float>(R * (((size_t)m->vocab + 3) & ~(size_t)3));      // rows padded to 16 bytes
     for (int i = 0; i < 2; ++i) {
         w.running[i] = a.take<float>(R); w.alive[i] = a.take<float>(R);
         w.hist[i] = a.take<int32_t>(R * T); w.lp[i] = a.take<float>(R * T); w.anc[i] = a.take<int32_t>(R * T);
@@ -359,7 +359,7 @@ int run_decode_step(Engine& e, Workspace& w, int B, int N, int k, int t, int ret
         ca.q = w.q; ca.ldq = hk;
         ca.kx = w.kx + (size_t)l * lv * B * N * hk; ca.vx = w.vx + (size_t)l * lv * B * N * hv;
         ca.level_stride = (size_t)B * N * hk; ca.ldkv = hk; ca.encmask = w.enc_mask; ca.n = N; ca.width = width;
-        ca.dk = m->d_k; ca.dv = m->d_v; ca.out = w.att; ca.out_level_stride = (size_t)rows * hv; ca.ldo = hv;
+        ca.heads = m->heads; ca.dk = m->d_k; ca.dv = m->d_v; ca.out = w.att; ca.out_level_stride = (size_t)rows * hv; ca.ldo = hv;
         TRY(ovc_decode_cross_attention(ca, B, m->heads, lv, s));
         float* ffn_in;
         if (m->dec_kind == OVC_DEC_MESHED) {
@@ -389,17 +389,22 @@ int run_decode_step(Engine& e, Workspace& w, int B, int N, int k, int t, int ret
 
     // ---- vocabulary projection, fused log-softmax + candidate scores + top-k, bookkeeping ---------
     e.gemm_class = 3;
-    ovc_lin fc{m->fc, nullptr};
-    TRY(e.linear(x, d, fc, nullptr, w.logits, rows, m->vocab, 0));
+    const int ldv = (m->vocab + 3) & ~3;            // 16-byte aligned logit rows: vector loads in the selection kernel
+    {
+        GemmArgs g{};
+        g.A1 = x; g.lda1 = d; g.K1 = d; g.M = rows; g.seg_n = m->vocab; g.nseg = 1; g.ldc = ldv;
+        g.seg[0] = GemmSegment{m->fc, nullptr, w.logits};
+        TRY(e.gemm(g));
+    }
     BeamSelectArgs bs{};
-    bs.logits = w.logits; bs.ld = m->vocab; bs.is_logp = 0;
+    bs.logits = w.logits; bs.ld = ldv; bs.is_logp = 0;
     bs.running = w.running[cur]; bs.alive = w.alive[cur]; bs.width = width; bs.V = m->vocab; bs.k = k;
     bs.chosen = w.chosen; bs.score = w.score;
     bs.masked_logp = return_probs ? w.all_buf + (size_t)t * R * m->vocab : nullptr;
     bs.row_max_out = w.row_max; bs.row_lsum_out = w.row_lsum;
     TRY(ovc_beam_select_launch(bs, B, s));
     BeamUpdateArgs bu{};
-    bu.chosen = w.chosen; bu.score = w.score; bu.logits = w.logits; bu.ld = m->vocab;
+    bu.chosen = w.chosen; bu.score = w.score; bu.logits = w.logits; bu.ld = ldv;
     bu.row_max = w.row_max; bu.row_lsum = w.row_lsum;
     bu.alive_in = w.alive[cur]; bu.alive_out = w.alive[nxt]; bu.running_out = w.running[nxt];
     bu.hist_in = w.hist[cur]; bu.hist_out = w.hist[nxt]; bu.lp_in = w.lp[cur]; bu.lp_out = w.lp[nxt];

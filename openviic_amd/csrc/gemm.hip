@@ -62,7 +62,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 }
 
 template <int BM, int BN, int WM, int WN, int WK, int BK>
-__global__ __launch_bounds__(256) void gemm_f32_mfma(GemmArgs p, int tiles_m, int tiles_n_per_seg) {
+__global__ __launch_bounds__(256) void gemm_f32_mfma(GemmArgs p, int tiles_m, int tiles_n_per_seg, int group_m) {
     using Cfg = TileConfig<BM, BN, WM, WN, WK, BK>;
     constexpr int LDT = Cfg::LDT;
     constexpr int kVecPerRow = BK / 4;               // float4 per tile row
@@ -76,9 +76,19 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma(GemmArgs p, int tiles_m, in
     const int wm = (wave / WN) % WM, wn = wave % WN;
 
     const int nwg = gridDim.x;
+    // Grouped order inside each XCD's contiguous chunk: super-rows of `group_m` M tiles are swept over
+    // all N tiles, M fastest inside the group.  The group's A tiles stay in that XCD's L2 for the whole
+    // sweep and each weight tile is fetched once per super-row; group_m == tiles_m (plain M-fastest) is
+    // used when all of A fits in L2 anyway.
     const int tile = xcd_remap(blockIdx.x, nwg);
-    const int tile_n_all = tile / tiles_m;           // M fastest: neighbours share the weight tile
-    const int tile_m = tile - tile_n_all * tiles_m;
+    const int tiles_n_all = nwg / tiles_m;
+    const int group_size = group_m * tiles_n_all;
+    const int group = tile / group_size;
+    const int first_m = group * group_m;
+    const int gm = min(group_m, tiles_m - first_m);
+    const int in_group = tile - group * group_size;
+    const int tile_n_all = in_group / gm;
+    const int tile_m = first_m + (in_group - tile_n_all * gm);
     const int seg = tile_n_all / tiles_n_per_seg;
     const int tile_n = tile_n_all - seg * tiles_n_per_seg;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
@@ -276,7 +286,10 @@ int launch_config(const GemmArgs& a, hipStream_t stream) {
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_f32_mfma<BM, BN, WM, WN, WK, BK>), dim3(grid), dim3(256), lds_bytes, stream, a, tiles_m, tiles_n);
+    // A panel larger than ~3 MB cannot stay in a 4 MB L2: sweep it in super-rows of 8 M tiles
+    const size_t a_bytes = sizeof(float) * (size_t)a.M * (a.K1 + a.K2);
+    const int group_m = a_bytes <= (size_t)3 << 20 ? tiles_m : (tiles_m < 8 ? tiles_m : 8);
+    hipLaunchKernelGGL((gemm_f32_mfma<BM, BN, WM, WN, WK, BK>), dim3(grid), dim3(256), lds_bytes, stream, a, tiles_m, tiles_n, group_m);
     OVC_RETURN_IF_LAUNCH_FAILED();
     return OVC_OK;
 }
@@ -424,6 +437,20 @@ extern "C" int ovc_gemm_tune(int M, int seg_n, int nseg, int K, void* scratch, s
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     if (rc != OVC_OK) return rc;
     if (best >= 0) g_tuned.push_back(TunedShape{M, seg_n, nseg, K, best});
+    return OVC_OK;
+}
+
+extern "C" int ovc_gemm_tuned_get(int M, int seg_n, int nseg, int K) {
+    for (const TunedShape& t : g_tuned)
+        if (t.M == M && t.seg_n == seg_n && t.nseg == nseg && t.K == K) return t.tiling;
+    return -1;
+}
+
+extern "C" int ovc_gemm_tuned_set(int M, int seg_n, int nseg, int K, int tiling) {
+    if (tiling < 0 || tiling >= kNumTilings || (nseg > 1 && seg_n % kTilings[tiling].bn)) return OVC_EINVAL;
+    for (TunedShape& t : g_tuned)
+        if (t.M == M && t.seg_n == seg_n && t.nseg == nseg && t.K == K) { t.tiling = tiling; return OVC_OK; }
+    g_tuned.push_back(TunedShape{M, seg_n, nseg, K, tiling});
     return OVC_OK;
 }
 

@@ -6,6 +6,8 @@ calls on the current stream -- independent batches issued on different streams o
 the engine; re-allocation (``.to()``) drops the engine (``BaseTransformer._apply``).
 """
 import ctypes
+import json
+import os
 
 import torch
 
@@ -47,7 +49,8 @@ def _ffn(dst, pwff):
 
 
 class CaptionEngine:
-    autotune = True      # measure GEMM tilings per shape on first use (one-off ~0.2 s, synchronises)
+    # measure GEMM tilings per shape on first use (one-off ~0.2 s, synchronises); OVC_AUTOTUNE=0 disables
+    autotune = os.environ.get("OVC_AUTOTUNE", "1") != "0"
 
     def __init__(self, model):
         self.lib = native.load()
@@ -136,6 +139,15 @@ class CaptionEngine:
         if key in self._tuned:
             return
         shapes = self.gemm_shapes(B, N, k)
+        cache_path = os.environ.get("OVC_TUNE_CACHE")       # optional json: {"M,seg_n,nseg,K": tiling}
+        cache = {}
+        if cache_path and os.path.exists(cache_path):
+            with open(cache_path) as f:
+                cache = json.load(f)
+            for shape in shapes:
+                name = ",".join(map(str, shape))
+                if name in cache:
+                    self.lib.ovc_gemm_tuned_set(*shape, int(cache[name]))
         need = max(4 * (m * kk + sn * ns * kk + m * sn * ns) + 256 for m, sn, ns, kk in shapes)
         scratch = torch.empty(need // 4 + 16, dtype=torch.float32, device=self.device).normal_()
         for m, sn, ns, kk in shapes:
@@ -143,6 +155,12 @@ class CaptionEngine:
                   "ovc_gemm_tune{}".format((m, sn, ns, kk)))
         torch.cuda.current_stream().synchronize()
         self._tuned.add(key)
+        if cache_path:
+            for shape in shapes:
+                cache[",".join(map(str, shape))] = self.lib.ovc_gemm_tuned_get(*shape)
+            os.makedirs(os.path.dirname(os.path.abspath(cache_path)), exist_ok=True)
+            with open(cache_path, "w") as f:
+                json.dump(cache, f, indent=0, sort_keys=True)
 
     # -- workspace ----------------------------------------------------------------------------
     def _get_workspace(self, B, N, k, return_probs):

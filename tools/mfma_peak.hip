@@ -1,33 +1,43 @@
-// Bare v_mfma_f32_32x32x2_f32 issue-rate probe: what fp32 MFMA rate does this chip sustain under load?
+// fp32 MFMA issue-rate probe: constant operands vs per-lane random operands (data-dependent power / clock).
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-__global__ __launch_bounds__(256) void mfma_loop(float* out, int iters, float a0, float b0) {
+__global__ __launch_bounds__(256) void mfma_loop(const float* in, float* out, int iters) {
     f32x16 acc0, acc1, acc2, acc3;
     for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; acc2[r] = 0.f; acc3[r] = 0.f; }
-    float a = a0 + threadIdx.x * 1e-3f, b = b0 - threadIdx.x * 1e-3f;
+    float v[8];
+    for (int j = 0; j < 8; ++j) v[j] = in[(blockIdx.x * 256 + threadIdx.x) * 8 + j];
     for (int i = 0; i < iters; ++i) {
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(b, a, acc1, 0, 0, 0);
-        acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, a, acc2, 0, 0, 0);
-        acc3 = __builtin_amdgcn_mfma_f32_32x32x2f32(b, b, acc3, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(v[0], v[1], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(v[2], v[3], acc1, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(v[4], v[5], acc2, 0, 0, 0);
+        acc3 = __builtin_amdgcn_mfma_f32_32x32x2f32(v[6], v[7], acc3, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(v[7], v[2], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(v[5], v[0], acc1, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(v[3], v[6], acc2, 0, 0, 0);
+        acc3 = __builtin_amdgcn_mfma_f32_32x32x2f32(v[1], v[4], acc3, 0, 0, 0);
     }
     float s = 0.f;
     for (int r = 0; r < 16; ++r) s += acc0[r] + acc1[r] + acc2[r] + acc3[r];
     out[blockIdx.x * 256 + threadIdx.x] = s;
 }
 int main() {
-    float* out; hipMalloc(&out, 4096 * 256 * 4);
-    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    for (int wgs : {256, 512, 1024}) {
+    const int wgs = 1024, n = wgs * 256 * 8;
+    float *in, *out, *h = (float*)malloc(n * 4);
+    (void)hipMalloc(&in, n * 4); (void)hipMalloc(&out, wgs * 256 * 4);
+    hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    for (int mode = 0; mode < 3; ++mode) {
+        for (int i = 0; i < n; ++i) h[i] = mode == 0 ? 0.f : mode == 1 ? 0.37f : (float)rand() / RAND_MAX * 2.f - 1.f;
+        (void)hipMemcpy(in, h, n * 4, hipMemcpyHostToDevice);
         const int iters = 20000;
-        for (int rep = 0; rep < 3; ++rep) {
-            hipEventRecord(e0);
-            hipLaunchKernelGGL(mfma_loop, dim3(wgs), dim3(256), 0, 0, out, iters, 0.37f, 0.61f);
-            hipEventRecord(e1); hipEventSynchronize(e1);
-            float ms; hipEventElapsedTime(&ms, e0, e1);
-            double flops = (double)wgs * 4 * iters * 4 * 4096.0;
-            printf("wgs=%d iters=%d: %.3f ms  %.1f TFLOP/s\n", wgs, iters, ms, flops / ms / 1e9);
+        for (int rep = 0; rep < 4; ++rep) {
+            (void)hipEventRecord(e0);
+            hipLaunchKernelGGL(mfma_loop, dim3(wgs), dim3(256), 0, 0, in, out, iters);
+            (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+            float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+            double flops = (double)wgs * 4 * iters * 8 * 4096.0;
+            printf("%s: %.3f ms  %.1f TFLOP/s\n", mode == 0 ? "zeros" : mode == 1 ? "constant" : "random", ms, flops / ms / 1e9);
         }
     }
     return 0;
