@@ -128,7 +128,7 @@ __global__ __launch_bounds__(kSelThreads) void beam_select_kernel(BeamSelectArgs
                 mx[i] = m;
                 float sum = 0.f;
 #pragma unroll
-                for (int j = 0; j < kElems; ++j) sum += expf(xv[i][j] - m);     // exp(-inf) = 0 for the tail
+                for (int j = 0; j < kElems; ++j) sum += __expf(xv[i][j] - m);   // v_exp_f32 path (|rel err| ~2e-7 per term); exp(-inf) = 0 for the tail
                 sum = wave_sum(sum);
                 if (lane == 0) red_sum[wave][i] = sum;
             }
