@@ -183,9 +183,10 @@ int ovc_beam_search(const ovc_model* m, const float* features, const float* boxe
                     int64_t* ids_out, float* logp_out, float* all_logp_out, ovc_stream stream);
 
 /* Optional device timing of the engine's GEMM launches (bench.py's roofline leg).  While enabled,
- * every GEMM launch is bracketed by hipEvents on its launch stream.  The bracket includes the
- * marker / dispatch latency (about 3 us per launch against rocprofv3's kernel duration); nothing
- * is subtracted, ovc_profile_overhead_ms reports the duration of an empty bracket for reference.  ovc_profile_read synchronises the events and
+ * every GEMM launch carries a pair of hipEvents on its launch stream (hipExtLaunchKernelGGL start /
+ * stop events, i.e. the dispatch's own begin / end timestamps, the quantity rocprofv3 reports as
+ * the kernel duration).  ovc_profile_overhead_ms reports the duration of an empty
+ * hipEventRecord pair for reference.  ovc_profile_read synchronises the events and
  * returns launches, total milliseconds and total algorithmic FLOPs (2*M*N*K), either per GEMM
  * class (kind 0: 0 feature projection, 1 encoder, 2 decoder projections/FFN, 3 vocabulary) or per
  * kernel instance (kind 1: tiling index, name from ovc_profile_kernel_name).  Enabling resets. */

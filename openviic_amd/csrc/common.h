@@ -53,6 +53,8 @@ struct GemmArgs {
 
 // Launches C = act([A1|A2] W^T + bias) + R on `stream`; returns an OVC_* code.
 int ovc_gemm_launch(const GemmArgs& args, hipStream_t stream);
+// Same launch with kernel-scoped events (dispatch begin / end timestamps) for profiling.
+int ovc_gemm_launch_timed(const GemmArgs& args, hipStream_t stream, hipEvent_t start, hipEvent_t stop);
 int ovc_gemm_pick_tiling(const GemmArgs& args);      // index of the tiling ovc_gemm_launch will use
 const char* ovc_gemm_tiling_name(int tiling);        // kernel name as rocprofv3 prints it
 

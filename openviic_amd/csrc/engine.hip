@@ -210,9 +210,8 @@ struct Engine {
         rec.flops = 2.0 * a.M * (double)a.seg_n * a.nseg * (a.K1 + a.K2);
         rec.cls = gemm_class;
         rec.tiling = ovc_gemm_pick_tiling(a);
-        (void)hipEventRecord(rec.start, stream);
-        const int rc = ovc_gemm_launch(a, stream);
-        (void)hipEventRecord(rec.stop, stream);
+        // kernel-scoped events: the dispatch's own begin / end timestamps (no marker latency in between)
+        const int rc = ovc_gemm_launch_timed(a, stream, rec.start, rec.stop);
         g_profile.push_back(rec);
         return rc;
     }

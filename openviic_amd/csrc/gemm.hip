@@ -24,6 +24,8 @@
 //     output pointers (fused q|k|v projections writing straight into the K/V caches).
 #include <vector>
 
+#include <hip/hip_ext.h>
+
 #include "common.h"
 
 namespace {
@@ -273,6 +275,10 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma(GemmArgs p, int tiles_m, in
     }
 }
 
+// Optional kernel-scoped timing events of the next launch (set by ovc_gemm_launch_timed): with them the launch
+// goes through hipExtLaunchKernelGGL, whose events take the dispatch packet's own begin / end timestamps.
+hipEvent_t g_launch_start = nullptr, g_launch_stop = nullptr;
+
 template <int BM, int BN, int WM, int WN, int WK, int BK>
 int launch_config(const GemmArgs& a, hipStream_t stream) {
     using Cfg = TileConfig<BM, BN, WM, WN, WK, BK>;
@@ -289,7 +295,11 @@ int launch_config(const GemmArgs& a, hipStream_t stream) {
     // A panel larger than ~3 MB cannot stay in a 4 MB L2: sweep it in super-rows of 8 M tiles
     const size_t a_bytes = sizeof(float) * (size_t)a.M * (a.K1 + a.K2);
     const int group_m = a_bytes <= (size_t)3 << 20 ? tiles_m : (tiles_m < 8 ? tiles_m : 8);
-    hipLaunchKernelGGL((gemm_f32_mfma<BM, BN, WM, WN, WK, BK>), dim3(grid), dim3(256), lds_bytes, stream, a, tiles_m, tiles_n, group_m);
+    if (g_launch_start && g_launch_stop)
+        hipExtLaunchKernelGGL((gemm_f32_mfma<BM, BN, WM, WN, WK, BK>), dim3(grid), dim3(256), (uint32_t)lds_bytes, stream,
+                              g_launch_start, g_launch_stop, 0, a, tiles_m, tiles_n, group_m);
+    else
+        hipLaunchKernelGGL((gemm_f32_mfma<BM, BN, WM, WN, WK, BK>), dim3(grid), dim3(256), lds_bytes, stream, a, tiles_m, tiles_n, group_m);
     OVC_RETURN_IF_LAUNCH_FAILED();
     return OVC_OK;
 }
@@ -370,6 +380,13 @@ int ovc_gemm_pick_tiling(const GemmArgs& a) {
         if (c < best) { best = c; pick = i; }
     }
     return pick;
+}
+
+int ovc_gemm_launch_timed(const GemmArgs& a, hipStream_t stream, hipEvent_t start, hipEvent_t stop) {
+    g_launch_start = start; g_launch_stop = stop;
+    const int rc = ovc_gemm_launch(a, stream);
+    g_launch_start = nullptr; g_launch_stop = nullptr;
+    return rc;
 }
 
 int ovc_gemm_launch(const GemmArgs& a, hipStream_t stream) {
