@@ -42,3 +42,28 @@ def test_reference_checkpoint_loads_key_for_key_and_oracle_reproduces_its_output
         ids, logp = OracleCaptioner(cfg, ckpt["state_dict"], len(vocab), vocab.max_caption_length).beam_search(feats, TINY_SHAPE["k"])
         assert torch.equal(ids, ckpt["beam_ids"])
         np.testing.assert_allclose(logp.numpy(), ckpt["beam_logp"].numpy(), rtol=1e-5, atol=5e-6)
+
+
+def test_feature_files_collate_like_the_reference(tmp_path):
+    """{image_id}.npy dicts (reference format) and .npz archives -> zero-padded batch."""
+    import pytest
+    from openviic_amd.data import batch_from_feature_files, load_feature_file
+    rng = np.random.default_rng(0)
+    paths = []
+    for i, n in enumerate((5, 3, 7)):
+        feats = {"region_features": rng.standard_normal((n, 8)).astype(np.float32),
+                 "region_boxes": rng.random((n, 4)).astype(np.float32), "unused_field": np.zeros(2)}
+        path = str(tmp_path / ("%d.npy" % i))
+        np.save(path, feats)                                   # what the reference's feature extractor writes
+        paths.append(path)
+    with pytest.raises(ValueError):
+        load_feature_file(paths[0])                            # pickled dict: must be opted into
+    batch = batch_from_feature_files(paths, trusted=True)
+    assert tuple(batch.region_features.shape) == (3, 7, 8) and tuple(batch.region_boxes.shape) == (3, 7, 4)
+    assert batch.region_features[1, 3:].abs().sum() == 0 and batch.region_features[1, :3].abs().sum() > 0
+    assert batch.filename == ["0.npy", "1.npy", "2.npy"] and batch.unused_field is None
+    mask = batch.region_features.sum(-1) == 0                  # models/utils.py:60: zero rows are padding
+    assert mask.sum(1).tolist() == [2, 4, 0]
+    npz = str(tmp_path / "9.npz")
+    np.savez(npz, region_features=np.ones((2, 8), np.float32))
+    assert load_feature_file(npz)["region_features"].shape == (2, 8)
