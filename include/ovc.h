@@ -8,8 +8,8 @@
  * dense row-major fp32 data unless stated otherwise; masks are one byte per element (0/1);
  * token ids are int64.  Nothing allocates, nothing synchronises, every launch goes to the
  * caller's hipStream_t; the return value is 0 on success or a negative OVC_E* code, and no
- * exception crosses the boundary.  The library keeps no global mutable state except the opt-in
- * profiling counters at the end of this header.
+ * exception crosses the boundary.  Process-wide state is limited to caches and opt-in tools:
+ * the GEMM tuning table, the hipGraph cache and the profiling counters.
  */
 #ifndef OVC_H_
 #define OVC_H_
@@ -181,6 +181,17 @@ int ovc_encode(const ovc_model* m, const float* features, const float* boxes, in
 int ovc_beam_search(const ovc_model* m, const float* features, const float* boxes, int B, int N,
                     int k, int out_size, void* workspace, size_t workspace_bytes,
                     int64_t* ids_out, float* logp_out, float* all_logp_out, ovc_stream stream);
+
+/* Same result as ovc_beam_search (without all_logp_out), issued as a hipGraph: the kernels that read
+ * the caller's features / boxes run as plain launches, everything else (encoder layers, every
+ * decode step, final ordering: ~740 launches whose arguments depend only on the model, the shapes
+ * and the workspace) is captured on the second call for a given (model contents, B, N, k, out_size,
+ * workspace) and replayed by hipGraphLaunch afterwards.  Graphs are cached process-wide
+ * (ovc_graph_cache_clear releases them); the workspace must stay allocated while they exist. */
+int ovc_beam_search_graph(const ovc_model* m, const float* features, const float* boxes, int B, int N,
+                          int k, int out_size, void* workspace, size_t workspace_bytes,
+                          int64_t* ids_out, float* logp_out, ovc_stream stream);
+int ovc_graph_cache_clear(void);
 
 /* Optional device timing of the engine's GEMM launches (bench.py's roofline leg).  While enabled,
  * every GEMM launch carries a pair of hipEvents on its launch stream (hipExtLaunchKernelGGL start /

@@ -12,6 +12,9 @@
 //   * beam re-ordering is an ancestor-slot table (int32 [rows, T]) read by the self-attention
 //     kernel; the reference physically gathers every cache (beam_search.py:19-34).
 #include <algorithm>
+#include <map>
+#include <mutex>
+#include <tuple>
 #include <vector>
 
 #include "common.h"
@@ -94,6 +97,7 @@ struct Workspace {
     float* running[2]; float* alive[2]; int32_t* hist[2]; float* lp[2]; int32_t* anc[2];
     int32_t* tok; int64_t* chosen; float* score; float* row_max; float* row_lsum; int32_t* order;
     float* all_buf;
+    int64_t* out_ids; float* out_logp;            // graph replay writes here, then copied to the caller
     size_t bytes;
 };
 
@@ -147,6 +151,7 @@ Workspace carve(const ovc_model* m, void* base, int B, int N, int k, int return_
     w.tok = a.take<int32_t>(R); w.chosen = a.take<int64_t>(R); w.score = a.take<float>(R);
     w.row_max = a.take<float>(R); w.row_lsum = a.take<float>(R); w.order = a.take<int32_t>(R);
     w.all_buf = a.take<float>(return_probs ? T * R * (size_t)m->vocab : 0);
+    w.out_ids = a.take<int64_t>(R * T); w.out_logp = a.take<float>(R * T);
     w.bytes = (a.off + 255) & ~(size_t)255;
     return w;
 }
@@ -253,20 +258,28 @@ struct Engine {
     }
 };
 
-int run_encoder(Engine& e, Workspace& w, const float* features, const float* boxes, int B, int N) {
+// The kernels that read caller-owned inputs (features, boxes): kept outside the captured graph, whose
+// nodes may only reference the workspace and the weights.
+int run_encoder_inputs(Engine& e, Workspace& w, const float* features, const float* boxes, int B, int N) {
     const ovc_model* m = e.m;
-    const int BN = B * N, d = m->d_model, hk = m->heads * m->d_k, hv = m->heads * m->d_v;
+    const int BN = B * N, d = m->d_model;
     hipStream_t s = e.stream;
     if (m->enc_kind == OVC_ENC_GEOMETRIC && (!boxes || !m->fc_g_w || !m->fc_g_b)) return OVC_EINVAL;
-
     e.gemm_class = 0;
     TRY(ovc_zero_row_mask(features, BN, m->d_feat, w.enc_mask, s));
     TRY(e.linear(features, m->d_feat, m->proj, nullptr, w.ey, BN, d, 0));
+    if (m->enc_kind == OVC_ENC_GEOMETRIC)
+        TRY(ovc_box_relation_weights(boxes, B, N, m->fc_g_w, m->fc_g_b, m->heads, m->d_g, m->trig, w.geometry, s));
+    return OVC_OK;
+}
+
+int run_encoder_layers(Engine& e, Workspace& w, int B, int N) {
+    const ovc_model* m = e.m;
+    const int BN = B * N, d = m->d_model, hk = m->heads * m->d_k, hv = m->heads * m->d_v;
+    hipStream_t s = e.stream;
     e.gemm_class = 1;
     TRY(ovc_region_position_encoding(nullptr, 1, N, d, 10000.0f, 0, 0.f, w.pe, s));
     TRY(ovc_layer_norm(w.ey, nullptr, m->enc_ln.g, m->enc_ln.b, w.pe, N, nullptr, m->ln_eps, w.xe[0], BN, d, s));
-    if (m->enc_kind == OVC_ENC_GEOMETRIC)
-        TRY(ovc_box_relation_weights(boxes, B, N, m->fc_g_w, m->fc_g_b, m->heads, m->d_g, m->trig, w.geometry, s));
 
     float* x = w.xe[0];
     float* x1 = w.xe[1];
@@ -292,6 +305,11 @@ int run_encoder(Engine& e, Workspace& w, const float* features, const float* box
         x = out;
     }
     return OVC_OK;
+}
+
+int run_encoder(Engine& e, Workspace& w, const float* features, const float* boxes, int B, int N) {
+    TRY(run_encoder_inputs(e, w, features, boxes, B, N));
+    return run_encoder_layers(e, w, B, N);
 }
 
 // Projected cross-attention keys/values of every decoder layer: one GEMM per encoder level with
@@ -471,6 +489,101 @@ extern "C" int ovc_beam_search(const ovc_model* m, const float* features, const 
     bf.k = k; bf.T = T; bf.out_size = out_size; bf.ids_out = ids_out; bf.logp_out = logp_out; bf.order_out = w.order;
     TRY(ovc_beam_finalize_launch(bf, B, e.stream));
     if (return_probs) TRY(ovc_beam_gather_all_launch(w.all_buf, w.order, B, k, T, m->vocab, all_logp_out, e.stream));
+    return OVC_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// hipGraph replay of the beam search: everything after the input-dependent kernels is a fixed
+// sequence of ~740 launches whose arguments (workspace, weights, shapes, step index) never change
+// for a given (model, B, N, k, workspace), so it is captured once and replayed.
+// ---------------------------------------------------------------------------------------------
+namespace {
+struct GraphKey {
+    uint64_t model_hash; const void* ws; int B, N, k, out_size;
+    bool operator<(const GraphKey& o) const {
+        return std::tie(model_hash, ws, B, N, k, out_size) < std::tie(o.model_hash, o.ws, o.B, o.N, o.k, o.out_size);
+    }
+};
+struct GraphEntry { int calls; bool unsupported; hipGraph_t graph; hipGraphExec_t exec; };
+std::map<GraphKey, GraphEntry> g_graphs;
+std::mutex g_graph_mutex;
+
+uint64_t hash_bytes(const void* p, size_t n) {
+    const unsigned char* b = static_cast<const unsigned char*>(p);
+    uint64_t h = 1469598103934665603ull;
+    for (size_t i = 0; i < n; ++i) { h ^= b[i]; h *= 1099511628211ull; }
+    return h;
+}
+
+int issue_decode_graph_body(Engine& e, Workspace& w, int B, int N, int k, int out_size) {
+    const ovc_model* m = e.m;
+    const int R = B * k, T = m->max_len;
+    TRY(run_encoder_layers(e, w, B, N));
+    TRY(project_cross_kv(e, w, B, N));
+    hipLaunchKernelGGL(init_beam_state_kernel, dim3((R + 255) / 256), dim3(256), 0, e.stream, w.running[0], w.alive[0], R);
+    OVC_RETURN_IF_LAUNCH_FAILED();
+    for (int t = 0; t < T; ++t) TRY(run_decode_step(e, w, B, N, k, t, 0));
+    const int fin = T & 1;
+    BeamFinalArgs bf{};
+    bf.running = w.running[fin]; bf.hist = w.hist[fin]; bf.lp = w.lp[fin];
+    bf.k = k; bf.T = T; bf.out_size = out_size; bf.ids_out = w.out_ids; bf.logp_out = w.out_logp; bf.order_out = w.order;
+    return ovc_beam_finalize_launch(bf, B, e.stream);
+}
+}  // namespace
+
+extern "C" int ovc_beam_search_graph(const ovc_model* m, const float* features, const float* boxes, int B, int N, int k,
+                                     int out_size, void* workspace, size_t workspace_bytes, int64_t* ids_out,
+                                     float* logp_out, ovc_stream stream) {
+    if (!model_ok(m) || !features || !workspace || !ids_out || !logp_out) return OVC_EINVAL;
+    if (B <= 0 || N <= 0 || N > 128 || k <= 0 || k > OVC_MAX_BEAM || out_size <= 0 || out_size > k) return OVC_EINVAL;
+    if ((long)m->vocab < k) return OVC_EINVAL;
+    if (!ovc_aligned16(features) || !ovc_aligned16(workspace)) return OVC_EINVAL;
+    Workspace w = carve(m, workspace, B, N, k, 0);
+    if (w.bytes > workspace_bytes) return OVC_EWORKSPACE;
+    Engine e{m, ovc_hip_stream(stream), 0};
+    const size_t out_n = (size_t)B * out_size * m->max_len;
+
+    const GraphKey key{hash_bytes(m, sizeof(*m)), workspace, B, N, k, out_size};
+    std::lock_guard<std::mutex> lock(g_graph_mutex);
+    GraphEntry& entry = g_graphs[key];
+    entry.calls += 1;
+
+    TRY(run_encoder_inputs(e, w, features, boxes, B, N));
+    // The legacy null stream cannot be captured (hipErrorStreamCaptureUnsupported): plain launches there.
+    if (e.stream == nullptr) entry.unsupported = true;
+    if (!entry.unsupported && !g_profile_on && entry.calls > 1 && !entry.exec) {
+        if (hipStreamBeginCapture(e.stream, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+            (void)hipGetLastError();
+            entry.unsupported = true;
+        } else {
+            const int rc = issue_decode_graph_body(e, w, B, N, k, out_size);
+            const hipError_t end = hipStreamEndCapture(e.stream, &entry.graph);
+            if (rc != OVC_OK || end != hipSuccess || !entry.graph ||
+                hipGraphInstantiate(&entry.exec, entry.graph, nullptr, nullptr, 0) != hipSuccess) {
+                (void)hipGetLastError();
+                if (entry.graph) (void)hipGraphDestroy(entry.graph);
+                entry.graph = nullptr; entry.exec = nullptr; entry.unsupported = true;
+            }
+        }
+    }
+    if (entry.exec && !g_profile_on) {
+        if (hipGraphLaunch(entry.exec, e.stream) != hipSuccess) return OVC_ELAUNCH;
+    } else {
+        // first call of a shape (warms every kernel's one-off attribute set-up), profiling, or no capture support
+        TRY(issue_decode_graph_body(e, w, B, N, k, out_size));
+    }
+    if (hipMemcpyAsync(ids_out, w.out_ids, sizeof(int64_t) * out_n, hipMemcpyDeviceToDevice, e.stream) != hipSuccess) return OVC_ELAUNCH;
+    if (hipMemcpyAsync(logp_out, w.out_logp, sizeof(float) * out_n, hipMemcpyDeviceToDevice, e.stream) != hipSuccess) return OVC_ELAUNCH;
+    return OVC_OK;
+}
+
+extern "C" int ovc_graph_cache_clear(void) {
+    std::lock_guard<std::mutex> lock(g_graph_mutex);
+    for (auto& kv : g_graphs) {
+        if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
+        if (kv.second.graph) (void)hipGraphDestroy(kv.second.graph);
+    }
+    g_graphs.clear();
     return OVC_OK;
 }
 

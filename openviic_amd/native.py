@@ -93,6 +93,9 @@ SIGNATURES = {
     "ovc_gemm_tuned_set": (c_int, [c_int, c_int, c_int, c_int, c_int]),
     "ovc_debug_force_gemm_tiling": (c_int, [c_int]),
     "ovc_debug_repeat_linear": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "ovc_beam_search_graph": (c_int, [POINTER(Model), c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_size_t,
+                                      c_void_p, c_void_p, c_void_p]),
+    "ovc_graph_cache_clear": (c_int, []),
     "ovc_profile_enable": (c_int, [c_int]),
     "ovc_profile_read": (c_int, [c_int, c_int, POINTER(c_int64), POINTER(c_double), POINTER(c_double)]),
     "ovc_profile_overhead_ms": (c_double, []),

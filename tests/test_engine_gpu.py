@@ -212,3 +212,25 @@ def test_batch_256_properties_other_architectures(variant):
     if boxes is None:
         same = (ids[:16].cpu().numpy() == g["B16_k5_ids"]).all(axis=1)
         assert same.mean() >= 0.9
+
+
+def test_hipgraph_replay_matches_plain_launches():
+    """From the third call of a shape on a non-default stream the decode launch sequence is replayed as a
+    hipGraph; results must be identical to plain launches, also when the input features change between calls."""
+    from openviic_amd.engine import CaptionEngine
+    cfg, vocab, sd, feats, _ = full_case("standard_transformer", 24)
+    model = device_model(cfg, vocab, sd)
+    eager = CaptionEngine(model)
+    eager.use_graph = False
+    graphed = CaptionEngine(model)
+    graphed.use_graph = True
+    stream = torch.cuda.Stream()
+    inputs = [feats[0:8].cuda(), feats[8:16].cuda(), feats[16:24].cuda(), feats[0:8].cuda()]
+    with torch.no_grad(), torch.cuda.stream(stream):
+        want = [eager.beam_search(x, None, 8, 5) for x in inputs]
+        got = [graphed.beam_search(x, None, 8, 5) for x in inputs]       # call 1 plain, 2 capture + launch, 3-4 replay
+    stream.synchronize()
+    for (wi, wl), (gi, gl) in zip(want, got):
+        assert torch.equal(wi, gi) and torch.equal(wl, gl)
+    assert not torch.equal(got[0][0], got[1][0])                          # different images, different captions
+    assert torch.equal(got[0][0], got[3][0])

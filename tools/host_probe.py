@@ -12,7 +12,8 @@ vocab = SyntheticVocab(10201, 20)
 model = build_model(model_config("standard_transformer", device="cuda"), vocab).eval()
 model.load_state_dict(synthetic_state_dict(model.state_dict()), strict=False)
 items = InstanceList(); items.region_features = synthetic_features(256, 50, 2048).cuda()
-with torch.no_grad():
+stream = torch.cuda.Stream()          # the default (null) stream cannot be captured into a hipGraph
+with torch.no_grad(), torch.cuda.stream(stream):
     for _ in range(3): model.beam_search(items, batch_size=256, beam_size=5)
     torch.cuda.synchronize()
     for rep in range(4):
