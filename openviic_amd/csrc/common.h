@@ -47,6 +47,7 @@ struct GemmArgs {
     int ldc;
     const float* R;      // residual [M, seg_n] (only with nseg == 1) or nullptr
     int ldr;
+    int res_mod;         // > 0: the residual has res_mod rows and row m reads row m % res_mod (broadcast over stacked blocks)
     int act;             // 0 none, 1 relu
     GemmSegment seg[OVC_MAX_SEGMENTS];
 };
@@ -130,3 +131,6 @@ struct BeamFinalArgs {
 int ovc_beam_finalize_launch(const BeamFinalArgs& p, int B, hipStream_t stream);
 int ovc_beam_gather_all_launch(const float* all_buf, const int* order, int B, int k, int T, int V, float* all_out,
                                hipStream_t stream);
+
+// out = (sum_l sigmoid(alpha[l]) * enc[l]) / divisor over `levels` stacked [n] blocks (rowops.hip)
+int ovc_meshed_mix(const float* alpha, const float* enc, int levels, long n, float divisor, float* out, hipStream_t stream);

@@ -90,7 +90,7 @@ struct Workspace {
     float* kx; float* vx;                         // [L][levels][B][N][h*dk|h*dv]
     // decoder
     float* x; float* x1; float* x2; float* y; float* q; float* att; float* ff; float* info; float* gate;
-    float* enc_att; float* alpha; float* mixed;
+    float* enc_att; float* alpha; float* mixed; float* ymesh;
     float* kc; float* vc;                         // [L][T][R][h*dk|h*dv]
     uint8_t* padflag;                             // [T][R]
     float* logits;                                // [R][V]
@@ -139,7 +139,8 @@ Workspace carve(const ovc_model* m, void* base, int B, int N, int k, int return_
     w.att = a.take<float>(lv * R * hv);
     w.ff = a.take<float>(R * m->d_ff);
     w.info = a.take<float>(R * d); w.gate = a.take<float>(R * d);
-    w.enc_att = a.take<float>(R * d); w.alpha = a.take<float>(R * d); w.mixed = a.take<float>(R * d);
+    w.enc_att = a.take<float>(lv * R * d); w.alpha = a.take<float>(lv * R * d); w.mixed = a.take<float>(R * d);
+    w.ymesh = a.take<float>(lv > 1 ? lv * R * d : 0);
     w.kc = a.take<float>(L * T * R * hk);
     w.vc = a.take<float>(L * T * R * hv);
     w.padflag = a.take<uint8_t>(T * R);
@@ -380,19 +381,34 @@ int run_decode_step(Engine& e, Workspace& w, int B, int N, int k, int t, int ret
         TRY(ovc_decode_cross_attention(ca, B, m->heads, lv, s));
         float* ffn_in;
         if (m->dec_kind == OVC_DEC_MESHED) {
-            // decoders.py:51-73: one shared enc_attn per level, sigmoid-gated sum / sqrt(levels)
-            for (int lvl = 0; lvl < lv; ++lvl) {
-                TRY(e.linear(w.att + (size_t)lvl * rows * hv, hv, dl.cross_att.o, w.x1, w.y, rows, d, 0));
-                TRY(ovc_layer_norm(w.y, nullptr, dl.cross_att.ln.g, dl.cross_att.ln.b, nullptr, 0, nullptr, m->ln_eps, w.enc_att, rows, d, s));
-                TRY(e.aoa(dl.cross_att, w.x1, w.enc_att, w.info, w.gate, rows));
-                GemmArgs g{};
-                g.A1 = w.x1; g.lda1 = d; g.K1 = d; g.A2 = w.enc_att; g.lda2 = d; g.K2 = d;
-                g.M = rows; g.seg_n = d; g.nseg = 1; g.ldc = d;
-                g.seg[0] = GemmSegment{dl.alpha[lvl].w, dl.alpha[lvl].b, w.alpha};
-                TRY(e.gemm(g));
-                TRY(ovc_gated_accumulate(lvl == 0 ? nullptr : w.mixed, w.alpha, w.enc_att,
-                                         lvl == lv - 1 ? sqrtf((float)lv) : 1.0f, w.mixed, (long)rows * d, s));
+            // decoders.py:51-73: one shared enc_attn per level, sigmoid-gated sum / sqrt(levels).  The levels'
+            // attention outputs are stacked [levels][rows][h*dv], so the shared output projection and its
+            // LayerNorm run once over levels*rows rows (the residual x1 is broadcast with res_mod).
+            const size_t nrd = (size_t)rows * d;
+            if (!dl.cross_att.aoa_i.w) {
+                GemmArgs o{};
+                o.A1 = w.att; o.lda1 = hv; o.K1 = hv; o.M = lv * rows; o.seg_n = d; o.nseg = 1; o.ldc = d;
+                o.R = w.x1; o.ldr = d; o.res_mod = rows;
+                o.seg[0] = GemmSegment{dl.cross_att.o.w, dl.cross_att.o.b, w.ymesh};
+                TRY(e.gemm(o));
+                TRY(ovc_layer_norm(w.ymesh, nullptr, dl.cross_att.ln.g, dl.cross_att.ln.b, nullptr, 0, nullptr, m->ln_eps,
+                                   w.enc_att, lv * rows, d, s));
+            } else {
+                for (int lvl = 0; lvl < lv; ++lvl) {      // AoA gates need the per-level pair (x1, enc_att_l)
+                    TRY(e.linear(w.att + (size_t)lvl * rows * hv, hv, dl.cross_att.o, w.x1, w.y, rows, d, 0));
+                    TRY(ovc_layer_norm(w.y, nullptr, dl.cross_att.ln.g, dl.cross_att.ln.b, nullptr, 0, nullptr, m->ln_eps,
+                                       w.enc_att + lvl * nrd, rows, d, s));
+                    TRY(e.aoa(dl.cross_att, w.x1, w.enc_att + lvl * nrd, w.info, w.gate, rows));
+                }
             }
+            for (int lvl = 0; lvl < lv; ++lvl) {
+                GemmArgs g{};
+                g.A1 = w.x1; g.lda1 = d; g.K1 = d; g.A2 = w.enc_att + lvl * nrd; g.lda2 = d; g.K2 = d;
+                g.M = rows; g.seg_n = d; g.nseg = 1; g.ldc = d;
+                g.seg[0] = GemmSegment{dl.alpha[lvl].w, dl.alpha[lvl].b, w.alpha + lvl * nrd};
+                TRY(e.gemm(g));
+            }
+            TRY(ovc_meshed_mix(w.alpha, w.enc_att, lv, (long)nrd, sqrtf((float)lv), w.mixed, s));
             ffn_in = w.mixed;
         } else {
             TRY(e.linear(w.att, hv, dl.cross_att.o, w.x1, w.y, rows, d, 0));

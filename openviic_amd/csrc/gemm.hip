@@ -255,7 +255,8 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma(GemmArgs p, int tiles_m, in
                 float res[16];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int mc = min(mbase + (r & 3) + 8 * (r >> 2), p.M - 1);
+                    int mc = min(mbase + (r & 3) + 8 * (r >> 2), p.M - 1);
+                    if (p.res_mod > 0) mc %= p.res_mod;
                     res[r] = p.R[(size_t)mc * p.ldr + nc];         // unconditional, clamped in-bounds
                 }
 #pragma unroll

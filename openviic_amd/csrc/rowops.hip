@@ -135,6 +135,24 @@ __global__ void gated_accumulate_kernel(const float* __restrict__ acc_in, const 
     }
 }
 
+// Meshed-decoder mix (decoders.py:59-68): out = ((s(a0) e0 + s(a1) e1) + ...) / sqrt(levels), accumulated in the
+// reference's order; alpha and enc are [levels][n] stacked.
+__global__ void meshed_mix_kernel(const float* __restrict__ alpha, const float* __restrict__ enc, int levels, long n4,
+                                  float divisor, float* __restrict__ out) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int l = 0; l < levels; ++l) {
+            const f32x4 al = reinterpret_cast<const f32x4*>(alpha)[(size_t)l * n4 + i];
+            const f32x4 xv = reinterpret_cast<const f32x4*>(enc)[(size_t)l * n4 + i];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] = acc[j] + sigmoidf_(al[j]) * xv[j];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] = acc[j] / divisor;
+        reinterpret_cast<f32x4*>(out)[i] = acc;
+    }
+}
+
 // y = x - logsumexp(x) per row; one 256-thread block per row (rows of ~10k vocabulary entries).
 __global__ __launch_bounds__(256) void log_softmax_kernel(const float* __restrict__ x, float* __restrict__ y, int rows, int n) {
     __shared__ float red[4];
@@ -253,6 +271,13 @@ extern "C" int ovc_gated_accumulate(const float* acc_in, const float* alpha, con
     if (!ovc_aligned16(alpha) || !ovc_aligned16(x) || !ovc_aligned16(acc_out) || (acc_in && !ovc_aligned16(acc_in))) return OVC_EINVAL;
     hipLaunchKernelGGL(gated_accumulate_kernel, dim3(elementwise_grid(n / 4)), dim3(256), 0, ovc_hip_stream(stream),
                        acc_in, alpha, x, divisor, acc_out, n / 4);
+    OVC_RETURN_IF_LAUNCH_FAILED();
+    return OVC_OK;
+}
+
+int ovc_meshed_mix(const float* alpha, const float* enc, int levels, long n, float divisor, float* out, hipStream_t stream) {
+    if (!alpha || !enc || !out || levels <= 0 || n <= 0 || (n & 3)) return OVC_EINVAL;
+    hipLaunchKernelGGL(meshed_mix_kernel, dim3(elementwise_grid(n / 4)), dim3(256), 0, stream, alpha, enc, levels, n / 4, divisor, out);
     OVC_RETURN_IF_LAUNCH_FAILED();
     return OVC_OK;
 }
