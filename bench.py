@@ -157,6 +157,11 @@ def main():
         return ids
 
     with torch.no_grad():
+        # engine set-up, not measurement: the first call of a (shape, stream) tunes the GEMM tilings and warms every
+        # kernel, the second captures the decode launch sequence as a hipGraph; from the third on it is replayed
+        for _ in range(3 * len(streams)):
+            step()
+        torch.cuda.synchronize()
         for _ in range(args.warmup):
             step()
         torch.cuda.synchronize()
