@@ -138,22 +138,24 @@ def main():
     if variant == "object_relation_transformer":
         items.region_boxes = synthetic_boxes(B * world, N_REGIONS, seed=0)[rank * B:(rank + 1) * B].to(device)
 
-    gathered = torch.empty(world * B, T, dtype=torch.int64, device=device) if distributed else None
 
     streams = [torch.cuda.Stream(device=device) for _ in range(max(1, args.streams))]
+    # one gather buffer per stream: batches in flight on different streams never share an output
+    gathered = [torch.empty(world * B, T, dtype=torch.int64, device=device) for _ in streams] if distributed else None
     issued = [0]
 
     def step():
         # consecutive batches are independent: alternate them over the streams (each stream has its own
         # engine workspace), so a batch's small decode launches overlap the other batch's
-        stream = streams[issued[0] % len(streams)]
+        slot = issued[0] % len(streams)
+        stream = streams[slot]
         issued[0] += 1
         with torch.cuda.stream(stream):
             ids, _ = model.beam_search(items, batch_size=B, beam_size=k, out_size=1)
             if distributed:
                 # the path's one exchange: token ids of every rank for evaluation (RCCL all-gather over xGMI,
                 # 40 KB per rank, on the decoding stream, once per batch)
-                dist.all_gather_into_tensor(gathered, ids.contiguous())
+                dist.all_gather_into_tensor(gathered[slot], ids.contiguous())
         return ids
 
     with torch.no_grad():
