@@ -45,8 +45,8 @@ GEMM_CLASSES = ["feature_proj", "encoder", "decoder_proj_ffn", "vocab"]
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=6)
     ap.add_argument("--config", default="standard_transformer")
     ap.add_argument("--batch", type=int, default=256, help="images per GPU per step")
     ap.add_argument("--beam", type=int, default=5)
