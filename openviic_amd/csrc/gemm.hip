@@ -191,6 +191,10 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma(GemmArgs p, int tiles_m, in
 #pragma unroll
             for (int j = 0; j < Cfg::TN; ++j)
                 b[j] = *reinterpret_cast<const f32x4*>(b_base + j * 32 * LDT + kk * 8);
+            // Raised priority around the MFMA cluster: hipcc then keeps the cluster contiguous instead of
+            // threading the next tile's loads / address arithmetic through it (+8..20 % on the 128x128 loop,
+            // tools/gemm_ablation.hip).
+            __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int s = 0; s < 4; ++s)
 #pragma unroll
@@ -198,6 +202,7 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma(GemmArgs p, int tiles_m, in
 #pragma unroll
                     for (int j = 0; j < Cfg::TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][s], b[j][s], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
         }
 
         if (kt + 1 < nkt) store_tile(buf ^ 1);
