@@ -58,6 +58,27 @@ def parse():
     return ap.parse_args()
 
 
+def profiled_gemm_traffic():
+    """HBM bytes per GEMM launch from the committed PMC passes (profiles/*_per_kernel_shape.csv, produced by
+    tools/profile_round.sh: separate FETCH_SIZE / WRITE_SIZE runs, FETCH_SIZE doubled as the gfx950 guide
+    prescribes), launch-weighted over the GEMM rows.  Not a live measurement: None when the file is absent."""
+    import csv
+    import glob
+    files = sorted(glob.glob(os.path.join(REPO, "profiles", "*_per_kernel_shape.csv")))
+    if not files:
+        return None, None
+    launches = total = 0.0
+    for row in csv.DictReader(open(files[-1])):
+        if not row["kernel"].startswith("gemm_f32_mfma") or not row["hbm_read_MB_per_launch"]:
+            continue
+        n = float(row["launches_per_batch"])
+        launches += n
+        total += n * (float(row["hbm_read_MB_per_launch"]) + float(row["hbm_write_MB_per_launch"] or 0.0)) * 1048576.0
+    if not launches:
+        return None, None
+    return round(total / launches, 0), os.path.basename(files[-1])
+
+
 def usable_cores():
     """Cores this process may really use: affinity mask and cgroup CPU quota, not the host total
     (a GPU box hands a 1-GPU job a share of the host, and oversubscribing it stalls OpenMP)."""
@@ -224,9 +245,12 @@ def main():
               % (captions_per_s, 1e3 * elapsed / args.steps, all_gemm, tot_n, 1e3 * tot_ms / max(tot_n, 1)),
               file=sys.stderr, flush=True)
         gflop = GFLOP_PER_CAPTION.get(variant)
+        traffic, traffic_source = profiled_gemm_traffic() if variant.startswith("standard") and B == 256 and k == 5 else (None, None)
         roofline = {"bound": "mfma", "kernel": "gemm_f32_mfma<BM,BN,WM,WN,WK,BK> (v_mfma_f32_32x32x2_f32), all tilings",
                     "achieved": round(all_gemm, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(all_gemm / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                    "frac": round(all_gemm / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
+                    "traffic_source": ("HBM bytes per launch (read + write), rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes: profiles/%s"
+                                       % traffic_source) if traffic else None,
                     "launches_per_step": tot_n, "avg_launch_us": round(1e3 * tot_ms / max(tot_n, 1), 2),
                     "flops_per_launch": round(tot_fl / max(tot_n, 1), 0), "kernel_ms_per_step": round(tot_ms, 3),
                     "timing": "hipExtLaunchKernelGGL start/stop events (dispatch begin/end timestamps) on the launch "

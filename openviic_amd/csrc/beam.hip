@@ -157,6 +157,11 @@ __global__ __launch_bounds__(kSelThreads) void beam_select_kernel(BeamSelectArgs
             const float run = p.running[b * W + i];
             const float alive = p.alive ? p.alive[b * W + i] : 1.0f;
             float* mrow = p.masked_logp ? p.masked_logp + ((size_t)b * W + i) * V : nullptr;
+            // seq_mask * candidate + frozen * (1 - seq_mask) (beam_search.py:52-55) with seq_mask in {0, 1}: a live
+            // beam's score is exactly run + lp (x + 0 == x), a frozen beam's exactly `frozen`; `alive` is uniform
+            // over the workgroup, so the branch is free.  A thread visits flat indices in increasing order, hence
+            // a strict > keeps the lower index on ties.
+            const bool live = alive != 0.0f;
 #pragma unroll
             for (int j = 0; j < kElems; ++j) {
                 const int c = kVec * (tid + (j / kVec) * kSelThreads) + (j % kVec);
@@ -164,10 +169,8 @@ __global__ __launch_bounds__(kSelThreads) void beam_select_kernel(BeamSelectArgs
                 if (c < V) {
                     const float lp = (xv[i][j] - mx[i]) - ls[i];
                     if (mrow) mrow[c] = lp * alive;
-                    // seq_mask * candidate + frozen * (1 - seq_mask), beam_search.py:52-55
-                    const float frozen = c == 0 ? run : -999.0f;
-                    cand = alive * (run + lp) + frozen * (1.0f - alive);
-                    if (better(cand, i * V + c, bv, bi)) { bv = cand; bi = i * V + c; }
+                    cand = live ? run + lp : (c == 0 ? run : -999.0f);
+                    if (cand > bv) { bv = cand; bi = i * V + c; }
                 }
                 xv[i][j] = cand;
             }
