@@ -4,12 +4,9 @@ Importing this package imports the module classes so that every registry is popu
 reference does in ``builders/__init__.py:1-2``.
 """
 from .registry import Registry
-from .attention_builder import META_ATTENTION, build_attention
-from .encoder_builder import META_ENCODER, build_encoder
-from .decoder_builder import META_DECODER, build_decoder
-from .vision_embedding_builder import META_VISION_EMBEDDING, build_vision_embedding
-from .text_embedding_builder import META_TEXT_EMBEDDING, build_text_embedding
-from .model_builder import META_ARCHITECTURE, build_model
+from .factories import (META_ARCHITECTURE, META_ATTENTION, META_DECODER, META_ENCODER, META_TEXT_EMBEDDING,
+                        META_VISION_EMBEDDING, build_attention, build_decoder, build_encoder, build_model,
+                        build_text_embedding, build_vision_embedding)
 
 from .. import modules as _modules            # noqa: F401  (registers module classes)
 from .. import architectures as _architectures  # noqa: F401  (registers model classes)

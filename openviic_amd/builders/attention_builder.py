@@ -1,8 +1,2 @@
-"""``build_attention(config)`` -- reference ``builders/attention_builder.py:3-8``."""
-from .registry import Registry
-
-META_ATTENTION = Registry("META_ATTENTION")
-
-
-def build_attention(config):
-    return META_ATTENTION.get(config.ARCHITECTURE)(config)
+"""Import path kept from the reference (``builders/attention_builder.py``); defined in ``factories.py``."""
+from .factories import META_ATTENTION, build_attention  # noqa: F401

@@ -1,8 +1,2 @@
-"""``build_decoder(config, vocab)`` -- reference ``builders/decoder_builder.py:3-8``."""
-from .registry import Registry
-
-META_DECODER = Registry("DECODER_LAYER")
-
-
-def build_decoder(config, vocab):
-    return META_DECODER.get(config.ARCHITECTURE)(config, vocab)
+"""Import path kept from the reference (``builders/decoder_builder.py``); defined in ``factories.py``."""
+from .factories import META_DECODER, build_decoder  # noqa: F401

@@ -1,8 +1,2 @@
-"""``build_encoder(config)`` -- reference ``builders/encoder_builder.py:3-8``."""
-from .registry import Registry
-
-META_ENCODER = Registry("ENCODER_LAYER")
-
-
-def build_encoder(config):
-    return META_ENCODER.get(config.ARCHITECTURE)(config)
+"""Import path kept from the reference (``builders/encoder_builder.py``); defined in ``factories.py``."""
+from .factories import META_ENCODER, build_encoder  # noqa: F401

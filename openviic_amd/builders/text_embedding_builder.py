@@ -1,8 +1,2 @@
-"""``build_text_embedding(config, vocab)`` -- reference ``builders/text_embedding_builder.py:3-8``."""
-from .registry import Registry
-
-META_TEXT_EMBEDDING = Registry("TEXT_EMBEDDING")
-
-
-def build_text_embedding(config, vocab):
-    return META_TEXT_EMBEDDING.get(config.ARCHITECTURE)(config, vocab)
+"""Import path kept from the reference (``builders/text_embedding_builder.py``); defined in ``factories.py``."""
+from .factories import META_TEXT_EMBEDDING, build_text_embedding  # noqa: F401

@@ -1,8 +1,2 @@
-"""``build_vision_embedding(config)`` -- reference ``builders/vision_embedding_builder.py:3-8``."""
-from .registry import Registry
-
-META_VISION_EMBEDDING = Registry("META_VISION_EMBEDDING")
-
-
-def build_vision_embedding(config):
-    return META_VISION_EMBEDDING.get(config.ARCHITECTURE)(config)
+"""Import path kept from the reference (``builders/vision_embedding_builder.py``); defined in ``factories.py``."""
+from .factories import META_VISION_EMBEDDING, build_vision_embedding  # noqa: F401
