@@ -110,31 +110,47 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma(GemmArgs p, int tiles_m, in
     // wave-uniform because K1 is a multiple of BK whenever K2 > 0.
     const bool k_tail = (K % BK) != 0 || (p.K1 % BK) != 0;   // uniform; false for every real shape
     bool a_ok = true, w_ok = true;
-    auto load_tile = [&](int kt) {
+
+    // Tile loads are raw buffer loads: the per-lane byte offset (row * ld + 4-float column group) is fixed for
+    // the whole K loop and the K position travels in the instruction's scalar offset, so the loop spends no
+    // vector instructions on addresses (+4..5 % on the 128x128 loop, tools/gemm_ablation.hip).  Rows past M / N
+    // fall outside the descriptor's range and read as zero; a K tail is zeroed when the registers go to LDS.
+    const __amdgpu_buffer_rsrc_t rsrc_a1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.A1), 0, p.M * p.lda1 * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_a2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.K2 ? p.A2 : p.A1), 0,
+                                                                              p.K2 ? p.M * p.lda2 * 4 : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(W), 0, p.seg_n * K * 4, 0x00020000);
+    int off_a1[Cfg::kLoadA], off_a2[Cfg::kLoadA], off_w[Cfg::kLoadB];
+    {
         const int kq = tid % kVecPerRow;
-        const int k0 = kt * BK;
-        const bool second = k0 >= p.K1;                       // uniform
-        const float* __restrict__ Ab = second ? p.A2 : p.A1;
-        const int lda = second ? p.lda2 : p.lda1;
-        const int klim = second ? p.K2 : p.K1;
-        const int ka = (second ? k0 - p.K1 : k0) + kq * 4;
-        const int kw = k0 + kq * 4;
-        a_ok = ka < klim;
-        w_ok = kw < K;
-        const int kac = min(ka, klim - 4);
-        const int kwc = min(kw, K - 4);
 #pragma unroll
         for (int i = 0; i < Cfg::kLoadA; ++i) {
-            const int row = tid / kVecPerRow + i * kRowsPerPass;
-            const int gm = min(m0 + row, p.M - 1);
-            stage_a[i] = *reinterpret_cast<const f32x4*>(Ab + (size_t)gm * lda + kac);
+            const int row = m0 + tid / kVecPerRow + i * kRowsPerPass;
+            off_a1[i] = (row * p.lda1 + kq * 4) * 4;
+            off_a2[i] = (row * p.lda2 + kq * 4) * 4;
         }
 #pragma unroll
-        for (int i = 0; i < Cfg::kLoadB; ++i) {
-            const int row = tid / kVecPerRow + i * kRowsPerPass;
-            const int gn = min(n0 + row, p.seg_n - 1);
-            stage_b[i] = *reinterpret_cast<const f32x4*>(W + (size_t)gn * K + kwc);
+        for (int i = 0; i < Cfg::kLoadB; ++i) off_w[i] = ((n0 + tid / kVecPerRow + i * kRowsPerPass) * K + kq * 4) * 4;
+    }
+    auto load_tile = [&](int kt) {
+        const int k0 = kt * BK;
+        const bool second = k0 >= p.K1;                       // uniform: which of A1 | A2 this K tile comes from
+        if (k_tail) {
+            const int kq = tid % kVecPerRow;
+            a_ok = (second ? k0 - p.K1 : k0) + kq * 4 < (second ? p.K2 : p.K1);
+            w_ok = k0 + kq * 4 < K;
         }
+        if (!second) {
+#pragma unroll
+            for (int i = 0; i < Cfg::kLoadA; ++i)
+                stage_a[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_a1, off_a1[i], k0 * 4, 0));
+        } else {
+#pragma unroll
+            for (int i = 0; i < Cfg::kLoadA; ++i)
+                stage_a[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_a2, off_a2[i], (k0 - p.K1) * 4, 0));
+        }
+#pragma unroll
+        for (int i = 0; i < Cfg::kLoadB; ++i)
+            stage_b[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, off_w[i], k0 * 4, 0));
     };
     // The loaded registers are first touched here, after the MFMA block of the previous tile, so the
     // global-load latency hides under the matrix work (issue early / write late).
@@ -405,6 +421,10 @@ int ovc_gemm_launch(const GemmArgs& a, hipStream_t stream) {
     for (int s = 0; s < a.nseg; ++s)
         if (!a.seg[s].W || !a.seg[s].C || !ovc_aligned16(a.seg[s].W)) return OVC_EINVAL;
     if (a.nseg > 1 && a.seg_n % 64) return OVC_EINVAL;   // a tile may not straddle two segments
+    // buffer descriptors address 32-bit byte ranges (rows past the end must stay representable)
+    const long kMaxBytes = 0x7fffffffL - (1L << 20);
+    if ((long)(a.M + 256) * a.lda1 * 4 > kMaxBytes || (a.K2 && (long)(a.M + 256) * a.lda2 * 4 > kMaxBytes) ||
+        (long)(a.seg_n + 256) * K * 4 > kMaxBytes) return OVC_EINVAL;
 
     const int pick = ovc_gemm_pick_tiling(a);
     switch (pick) {

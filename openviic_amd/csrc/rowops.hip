@@ -75,29 +75,31 @@ __global__ __launch_bounds__(256) void zero_row_mask_kernel(const float* __restr
     if (lane == 0) mask[row] = (s == 0.f) ? 1 : 0;
 }
 
-// DETR-style sinusoid over the region index.
+// DETR-style sinusoid over the region index; one thread per output element.
 __global__ void region_pe_kernel(const uint8_t* __restrict__ mask, int b, int n, int d, float temperature,
                                  int normalize, float scale, float* __restrict__ pe) {
-    const int bi = blockIdx.x;
-    for (int idx = threadIdx.x; idx < n * d; idx += blockDim.x) {
-        const int i = idx / d, c = idx - i * d;
-        float pos, last;
-        if (mask) {
-            int cnt = 0, tot = 0;
-            for (int j = 0; j < n; ++j) {
-                const int keep = mask[bi * n + j] ? 0 : 1;
-                tot += keep;
-                if (j <= i) cnt += keep;
-            }
-            pos = (float)cnt; last = (float)tot;
-        } else {
-            pos = (float)(i + 1); last = (float)n;
+    const long total = (long)b * n * d;
+    const long idx = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int c = (int)(idx % d);
+    const int i = (int)((idx / d) % n);
+    const int bi = (int)(idx / ((long)n * d));
+    float pos, last;
+    if (mask) {
+        int cnt = 0, tot = 0;
+        for (int j = 0; j < n; ++j) {
+            const int keep = mask[bi * n + j] ? 0 : 1;
+            tot += keep;
+            if (j <= i) cnt += keep;
         }
-        if (normalize) pos = pos / (last + 1e-6f) * scale;
-        const float div = powf(temperature, (float)(2 * (c / 2)) / (float)d);
-        const float ang = pos / div;
-        pe[((size_t)bi * n + i) * d + c] = (c & 1) ? cosf(ang) : sinf(ang);
+        pos = (float)cnt; last = (float)tot;
+    } else {
+        pos = (float)(i + 1); last = (float)n;
     }
+    if (normalize) pos = pos / (last + 1e-6f) * scale;
+    const float div = powf(temperature, (float)(2 * (c / 2)) / (float)d);
+    const float ang = pos / div;
+    pe[idx] = (c & 1) ? cosf(ang) : sinf(ang);
 }
 
 __global__ __launch_bounds__(256) void embed_kernel(const int64_t* __restrict__ tokens, const int64_t* __restrict__ positions,
@@ -237,8 +239,9 @@ extern "C" int ovc_zero_row_mask(const float* x, int rows, int d, uint8_t* mask,
 extern "C" int ovc_region_position_encoding(const uint8_t* mask, int b, int n, int d, float temperature,
                                             int normalize, float scale, float* pe, ovc_stream stream) {
     if (!pe || b <= 0 || n <= 0 || d <= 0) return OVC_EINVAL;
-    hipLaunchKernelGGL(region_pe_kernel, dim3(b), dim3(256), 0, ovc_hip_stream(stream), mask, b, n, d, temperature,
-                       normalize, scale, pe);
+    const long total = (long)b * n * d;
+    hipLaunchKernelGGL(region_pe_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ovc_hip_stream(stream), mask, b, n, d,
+                       temperature, normalize, scale, pe);
     OVC_RETURN_IF_LAUNCH_FAILED();
     return OVC_OK;
 }

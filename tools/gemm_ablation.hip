@@ -20,7 +20,24 @@ __global__ __launch_bounds__(256) void gemm(const float* __restrict__ A, const f
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     constexpr int kBuf = (BM + BN) * LDT;
     f32x4 sa[4], sb[4];
+    // bit 6: raw buffer loads -- per-lane byte offset fixed for the whole K loop, the K position is a scalar offset
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(A), 0, (int)((size_t)M * K * 4 > 0x7fffffffu ? 0x7fffffff : (size_t)M * K * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(W), 0, (int)((size_t)N * K * 4 > 0x7fffffffu ? 0x7fffffff : (size_t)N * K * 4), 0x00020000);
+    int voa[4], vob[4];
+    for (int i = 0; i < 4; ++i) {
+        const int row = (tid >> 3) + i * 32;
+        voa[i] = ((m0 + row) * K + (tid & 7) * 4) * 4;
+        vob[i] = ((n0 + row) * K + (tid & 7) * 4) * 4;
+    }
     auto load = [&](int kt) {
+        if (ABL & 64) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                sa[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ra, voa[i], kt * BK * 4, 0));
+                sb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rw, vob[i], kt * BK * 4, 0));
+            }
+            return;
+        }
         const int kq = tid & 7, k = kt * BK + kq * 4;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -117,7 +134,7 @@ template <int ABL> void run(const float* A, const float* W, float* C, int M, int
         const float tf = 4 * 2.0 * M * N * K / ms / 1e9;
         if (rep && tf > best) best = tf;
     }
-    printf("ablation %d (%s%s%s%s%s): %.1f TFLOP/s\n", ABL, ABL & 1 ? "no-gload " : "", ABL & 2 ? "no-ldswrite/barrier " : "", ABL & 4 ? "no-ldsread " : "", ABL & 8 ? "stagger " : "", ABL & 16 ? "setprio " : "", best); if (ABL & 32) printf("   (with fragment ping-pong)\n");
+    printf("ablation %d (%s%s%s%s%s): %.1f TFLOP/s\n", ABL, ABL & 1 ? "no-gload " : "", ABL & 2 ? "no-ldswrite/barrier " : "", ABL & 4 ? "no-ldsread " : "", ABL & 8 ? "stagger " : "", ABL & 16 ? "setprio " : "", best); if (ABL & 32) printf("   (with fragment ping-pong)\n"); if (ABL & 64) printf("   (buffer loads, scalar k offset)\n");
 }
 int main() {
     const int M = 8192, N = 8192, K = 512;
@@ -125,6 +142,6 @@ int main() {
     (void)hipMalloc(&A, (size_t)M * K * 4); (void)hipMalloc(&W, (size_t)N * K * 4); (void)hipMalloc(&C, (size_t)M * N * 4);
     for (size_t i = 0; i < (size_t)M * K; ++i) h[i] = (float)rand() / RAND_MAX * 2.f - 1.f;
     (void)hipMemcpy(A, h, (size_t)M * K * 4, hipMemcpyHostToDevice); (void)hipMemcpy(W, h, (size_t)N * K * 4, hipMemcpyHostToDevice);
-    run<0>(A, W, C, M, N, K); run<16>(A, W, C, M, N, K); run<32>(A, W, C, M, N, K); run<48>(A, W, C, M, N, K); run<16>(A, W, C, M, N, K); run<48>(A, W, C, M, N, K);
+    run<16>(A, W, C, M, N, K); run<80>(A, W, C, M, N, K); run<16>(A, W, C, M, N, K); run<80>(A, W, C, M, N, K); run<16>(A, W, C, M, N, K); run<80>(A, W, C, M, N, K);
     return 0;
 }
