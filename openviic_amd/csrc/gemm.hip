@@ -253,46 +253,52 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma(GemmArgs p, int tiles_m, in
     }
 
     // Epilogue.  D layout of the 32x32 tile: col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+    // Branch-free epilogue on buffer descriptors: one per-lane byte offset (first row of the lane's 16, its
+    // column) and a scalar row offset per accumulator register; rows past M fall outside the descriptor and
+    // are dropped by the hardware, columns past seg_n get an out-of-range offset.
     const float* __restrict__ bias = p.seg[seg].bias;
     float* __restrict__ C = p.seg[seg].C;
     const int half = lane >> 5;
     const bool has_res = p.R != nullptr;                          // uniform
-    const bool interior = m0 + BM <= p.M && n0 + BN <= p.seg_n;   // uniform: no bounds checks needed
+    const __amdgpu_buffer_rsrc_t rsrc_c = __builtin_amdgcn_make_buffer_rsrc(C, 0, p.M * p.ldc * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(has_res ? p.R : p.A1), 0,
+                                                                             has_res && p.res_mod == 0 ? p.M * p.ldr * 4 : 0, 0x00020000);
+    constexpr int kOutOfRange = 0x7ffffff0;
 #pragma unroll
     for (int j = 0; j < Cfg::TN; ++j) {
         const int n = n0 + wn * Cfg::kWaveN + j * 32 + (lane & 31);
-        const int nc = min(n, p.seg_n - 1);
-        const float bv = bias ? bias[nc] : 0.f;
+        const bool n_ok = n < p.seg_n;
+        const float bv = bias ? bias[min(n, p.seg_n - 1)] : 0.f;
 #pragma unroll
         for (int i = 0; i < Cfg::TM; ++i) {
             const int mbase = m0 + wm * Cfg::kWaveM + i * 32 + 4 * half;
             float out[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                float v = acc[i][j][r] + bv;
+                const float v = acc[i][j][r] + bv;
                 out[r] = p.act == 1 ? fmaxf(v, 0.f) : v;
             }
             if (has_res) {
                 float res[16];
+                if (p.res_mod == 0) {
+                    const int voff_r = n_ok ? (mbase * p.ldr + n) * 4 : kOutOfRange;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    int mc = min(mbase + (r & 3) + 8 * (r >> 2), p.M - 1);
-                    if (p.res_mod > 0) mc %= p.res_mod;
-                    res[r] = p.R[(size_t)mc * p.ldr + nc];         // unconditional, clamped in-bounds
+                    for (int r = 0; r < 16; ++r)
+                        res[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc_r, voff_r, ((r & 3) + 8 * (r >> 2)) * p.ldr * 4, 0));
+                } else {                                           // residual broadcast over stacked row blocks
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int mc = min(mbase + (r & 3) + 8 * (r >> 2), p.M - 1) % p.res_mod;
+                        res[r] = p.R[(size_t)mc * p.ldr + min(n, p.seg_n - 1)];
+                    }
                 }
 #pragma unroll
                 for (int r = 0; r < 16; ++r) out[r] += res[r];
             }
-            if (interior) {
+            const int voff_c = n_ok ? (mbase * p.ldc + n) * 4 : kOutOfRange;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) C[(size_t)(mbase + (r & 3) + 8 * (r >> 2)) * p.ldc + n] = out[r];
-            } else {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int m = mbase + (r & 3) + 8 * (r >> 2);
-                    if (m < p.M && n < p.seg_n) C[(size_t)m * p.ldc + n] = out[r];
-                }
-            }
+            for (int r = 0; r < 16; ++r)
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, out[r]), rsrc_c, voff_c, ((r & 3) + 8 * (r >> 2)) * p.ldc * 4, 0);
         }
     }
 }
@@ -424,7 +430,8 @@ int ovc_gemm_launch(const GemmArgs& a, hipStream_t stream) {
     // buffer descriptors address 32-bit byte ranges (rows past the end must stay representable)
     const long kMaxBytes = 0x7fffffffL - (1L << 20);
     if ((long)(a.M + 256) * a.lda1 * 4 > kMaxBytes || (a.K2 && (long)(a.M + 256) * a.lda2 * 4 > kMaxBytes) ||
-        (long)(a.seg_n + 256) * K * 4 > kMaxBytes) return OVC_EINVAL;
+        (long)(a.seg_n + 256) * K * 4 > kMaxBytes || (long)(a.M + 256) * a.ldc * 4 > kMaxBytes ||
+        (a.R && (long)(a.M + 256) * a.ldr * 4 > kMaxBytes)) return OVC_EINVAL;
 
     const int pick = ovc_gemm_pick_tiling(a);
     switch (pick) {
