@@ -45,7 +45,7 @@ for counter in ("FETCH_SIZE", "WRITE_SIZE", "SQ_VALU_MFMA_BUSY_CYCLES"):
         cell[1] += float(r["Counter_Value"])
     pmc[counter] = agg
 
-nbatch = float(sys.argv[2]) if len(sys.argv) > 2 else 9.0      # 6 steps + 2 warm-up + 1 instrumented pass
+nbatch = float(sys.argv[2]) if len(sys.argv) > 2 else 12.0     # 3 set-up calls + 2 warm-up + 6 steps + 1 instrumented pass
 rows = []
 for (kernel, wgs), durs in sorted(per.items(), key=lambda kv: -sum(kv[1])):
     durs.sort()
