@@ -256,6 +256,23 @@ def main():
                     "timing": "hipExtLaunchKernelGGL start/stop events (dispatch begin/end timestamps) on the launch "
                               "stream for every GEMM launch of one instrumented batch after the timed region",
                     "per_kernel": per_kernel, "per_class": per_class}
+        # K1: the padding-mask kernel is the path's one HBM-bound pass over the
+        # features (B*N*d_feat fp32 in, B*N bytes out); torch events on the stream it is launched on.
+        from openviic_amd import ops
+        feats = items.region_features
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for _ in range(3):
+            ops.zero_row_mask(feats)
+        ev0.record()
+        for _ in range(20):
+            ops.zero_row_mask(feats)
+        ev1.record()
+        torch.cuda.synchronize()
+        k1_us = ev0.elapsed_time(ev1) / 20 * 1e3
+        k1_bytes = feats.numel() * 4 + feats.shape[0] * feats.shape[1]
+        roofline["k1_hbm"] = {"kernel": "zero_row_mask_kernel", "bound": "hbm", "bytes_per_launch": k1_bytes,
+                              "avg_us": round(k1_us, 2), "achieved": round(k1_bytes / k1_us / 1e3, 1), "peak": 8000.0,
+                              "unit": "GB/s", "frac": round(k1_bytes / k1_us / 1e3 / 8000.0, 4)}
         if gflop:
             e2e = captions_per_s / world * gflop / 1e3
             roofline["end_to_end"] = {"gflop_per_caption": gflop, "achieved": round(e2e, 2),

@@ -129,3 +129,18 @@ def model_config(variant: str, *, d_feature: int = 2048, d_model: int = 512, hea
                                "WORD_EMBEDDING_CACHE": None, "DROPOUT": 0.1},
         },
     })
+
+
+def dual_collaborative_config(*, d_region: int = 2048, d_grid: int = 2048, d_model: int = 512, heads: int = 8,
+                              d_kv: int = 64, d_ff: int = 2048, layers: int = 3,
+                              trignometric_embedding: bool = False):
+    """``(VISION_EMBEDDING, ENCODER)`` nodes of the dual-collaborative (DLCT) encoder: the keys that
+    ``GeometricDualFeatureEmbedding`` (reference ``vision_embeddings.py:47-55``) and
+    ``DualCollaborativeLevelEncoder`` (``encoders.py:116-144``) read.  The reference ships no yaml for them."""
+    att = _attention("AugmentedGeometryScaledDotProductAttention", d_model, heads, d_kv, d_ff, False, False)
+    embedding = ConfigNode({"ARCHITECTURE": "GeometricDualFeatureEmbedding", "D_REGION_FEATURE": d_region,
+                            "D_GRID_FEATURE": d_grid, "D_MODEL": d_model, "DROPOUT": 0.1})
+    encoder = ConfigNode({"ARCHITECTURE": "DualCollaborativeLevelEncoder", "D_MODEL": d_model, "HEAD": heads,
+                          "LAYERS": layers, "TRIGNOMETRIC_EMBEDDING": trignometric_embedding,
+                          "SELF_ATTENTION": dict(att), "CROSS_ATTENTION": dict(att)})
+    return embedding, encoder

@@ -114,3 +114,19 @@ def synthetic_boxes(batch: int, regions: int = 50, seed: int = 0) -> torch.Tenso
     xy = torch.rand(batch, regions, 2, generator=g) * 0.5
     wh = torch.rand(batch, regions, 2, generator=g) * 0.5
     return torch.cat([xy, xy + wh], dim=-1)
+
+
+def synthetic_dual_inputs(batch: int, regions: int, grid: int, d_region: int, d_grid: int, seed: int = 0):
+    """Inputs of the dual-collaborative encoder: ragged region features with boxes (padding = zero rows and zero
+    boxes), full ``grid x grid`` features and the cell boxes ``(c/g, r/g, (c+1)/g, (r+1)/g)`` in row-major order.
+    Two boxes of image 0 are fixed: one covering every cell, one with all corners exactly on cell edges."""
+    region = synthetic_features(batch, regions, d_region, seed=seed, ragged=True)
+    cells = synthetic_features(batch, grid * grid, d_grid, seed=seed + 1)
+    boxes = synthetic_boxes(batch, regions, seed=seed)
+    boxes[region.abs().sum(-1) == 0] = 0
+    boxes[0, 0] = torch.tensor([0.0, 0.0, 0.999, 0.999])
+    boxes[0, 1] = torch.tensor([1.0 / grid, 2.0 / grid, 1.0 / grid, 2.0 / grid])
+    edge = torch.arange(grid, dtype=torch.float32) / grid
+    ys, xs = torch.meshgrid(edge, edge, indexing="ij")
+    cell_boxes = torch.stack([xs, ys, xs + 1.0 / grid, ys + 1.0 / grid], dim=-1).reshape(1, grid * grid, 4)
+    return region, boxes, cells, cell_boxes.repeat(batch, 1, 1)

@@ -24,6 +24,8 @@ Fixture families:
   G5  box relation embedding for both ``trignometric_embedding`` values
   G6  ids -> caption strings through the reference's ``Vocab.decode_caption`` + duplicate collapse
   G7  a checkpoint written by the reference (its own initialisation) with its beam-search output
+  G8  dual-collaborative (DLCT) embedding + encoder: the reference's own sub-modules composed
+      harness-side with the three mask-shape repairs listed in ``g8_dlct_encoder``
 """
 import argparse
 import os
@@ -311,6 +313,101 @@ def g7_reference_checkpoint(ref, out_dir):
         print("wrote g7_reference_checkpoint_%s.pth (%d tensors)" % (variant, len(model.state_dict())))
 
 
+DLCT_TINY = dict(B=3, n_regions=7, grid=3, d_region=32, d_grid=24, d_model=64, heads=4, d_kv=16, d_ff=128, layers=2)
+
+
+def dlct_config(t, trig):
+    from openviic_amd.config import dual_collaborative_config
+    return dual_collaborative_config(d_region=t["d_region"], d_grid=t["d_grid"], d_model=t["d_model"], heads=t["heads"],
+                                     d_kv=t["d_kv"], d_ff=t["d_ff"], layers=t["layers"], trignometric_embedding=trig)
+
+
+def dlct_inputs(t, seed):
+    from openviic_amd.utils.synthetic import synthetic_dual_inputs
+    return synthetic_dual_inputs(t["B"], t["n_regions"], t["grid"], t["d_region"], t["d_grid"], seed=seed)
+
+
+def g8_dlct_encoder(ref, out_dir):
+    """The reference ships ``GeometricDualFeatureEmbedding`` and ``DualCollaborativeLevelEncoder``
+    (vision_embeddings.py:46-71, encoders.py:115-211) but neither runs.  The
+    fixture is produced by the reference's own sub-modules -- projections, ``get_combine_masks``,
+    ``box_relational_embedding``, ``fc_gs``, layer norms, positional embedding, the self-attention
+    ``EncoderLayer``s as they are, and ``mhatt`` / ``pwff`` of the cross layers -- composed here in the order of
+    the reference's ``forward`` with three repairs:
+      1. ``get_combine_masks`` returns (B,1,1,n,g*g); the embedding treats it as 4-D: use (B,1,n,g*g);
+      2. the key-padding masks (B,1,1,n) are expanded over the query dimension before they are
+         concatenated with the region<->grid visibility masks;
+      3. a cross ``EncoderLayer`` clears padded rows with ``padding_mask.squeeze(1).squeeze(1)``, which cannot
+         broadcast for a per-query mask: clear the rows of the *query* side's padding mask instead.
+    """
+    from models.modules.encoders import DualCollaborativeLevelEncoder
+    from models.modules.vision_embeddings import GeometricDualFeatureEmbedding
+    from models.utils import box_relational_embedding, generate_padding_mask, get_combine_masks
+    import torch.nn.functional as F
+    t = DLCT_TINY
+    for trig in (False, True):
+        emb_cfg, enc_cfg = dlct_config(t, trig)
+        emb = GeometricDualFeatureEmbedding(emb_cfg).eval()
+        enc = DualCollaborativeLevelEncoder(enc_cfg).eval()
+        emb.load_state_dict(synthetic_state_dict(emb.state_dict(), seed=51, mode="generic"))
+        enc.load_state_dict(synthetic_state_dict(enc.state_dict(), seed=52, mode="generic"))
+        region, region_boxes, grid, grid_boxes = dlct_inputs(t, seed=61)
+        B, n, gg = t["B"], t["n_regions"], t["grid"] ** 2
+        store = {}
+        with torch.no_grad():
+            # ---- embedding (vision_embeddings.py:56-71) ----
+            region_mask = generate_padding_mask(region, padding_idx=0)
+            grid_mask = generate_padding_mask(grid, padding_idx=0)
+            r2g = get_combine_masks(region_boxes, t["grid"]).reshape(B, 1, n, gg)                      # repair 1
+            region2all = torch.cat([region_mask.expand(B, 1, n, n), r2g], dim=-1)                      # repair 2
+            grid2all = torch.cat([r2g.permute(0, 1, 3, 2), grid_mask.expand(B, 1, gg, gg)], dim=-1)
+            rf, gf = emb.region_proj(region), emb.grid_proj(grid)
+            store.update(region_embedded=rf, grid_embedded=gf, region_mask=region_mask, grid_mask=grid_mask,
+                         region2all_mask=region2all, grid2all_mask=grid2all)
+            # ---- encoder (encoders.py:153-211) ----
+            boxes = torch.cat([region_boxes, grid_boxes], dim=1)
+            rel = box_relational_embedding(boxes, dim_g=enc.d_g, trignometric_embedding=enc.trignometric_embedding)
+            nk = rel.shape[1]
+            w = torch.cat([fc(rel.view(-1, enc.d_g)).view(B, 1, nk, nk) for fc in enc.fc_gs], dim=1)
+            w = F.relu(w)
+            rf = enc.layer_norm_region(rf) + enc.pos_embedding(rf)
+            gf = enc.layer_norm_grid(gf) + enc.pos_embedding(gf)
+            for li, (l_r, l_g, l_r2g, l_g2r) in enumerate(zip(enc.layers_region, enc.layers_grid, enc.region2grid, enc.grid2region)):
+                rf = l_r(queries=rf, keys=rf, values=rf, relative_geometry_weights=w[:, :, :n, :n],
+                         padding_mask=region_mask, attention_mask=region_mask)
+                gf = l_g(queries=gf, keys=gf, values=gf, relative_geometry_weights=w[:, :, n:, n:],
+                         padding_mask=grid_mask, attention_mask=grid_mask)
+                combined = torch.cat([rf, gf], dim=1)
+                combined = combined + enc.pos_embedding(combined)
+
+                def cross(layer, q, geo, mask, q_pad):
+                    att = layer.mhatt(queries=q, keys=combined, values=combined, padding_mask=mask,
+                                      attention_mask=mask, relative_geometry_weights=geo)
+                    return layer.pwff(att).masked_fill(q_pad[:, 0, 0, :, None], 0)                     # repair 3
+                rf = cross(l_r2g, rf, w[:, :, :n, :], region2all, region_mask)
+                gf = cross(l_g2r, gf, w[:, :, n:, :], grid2all, grid_mask)
+                store["layer%d_region" % li], store["layer%d_grid" % li] = rf, gf
+            store["out"] = torch.cat([rf, gf], dim=1)
+            store["padding_mask"] = torch.cat([region_mask, grid_mask], dim=-1)
+            store["geometry_weights"] = w
+        data = {k: v.numpy() for k, v in store.items()}
+        data.update(region_features=region.numpy(), region_boxes=region_boxes.numpy(), grid_features=grid.numpy(),
+                    grid_boxes=grid_boxes.numpy())
+        # cell look-up at float32 values next to the (float64) cell edges, on a 10 x 10 grid
+        edges = torch.tensor([0.0, 0.1, 0.3, 0.7, 0.9, 0.5, 0.2, 0.6], dtype=torch.float32)
+        near = torch.stack([edges, torch.nextafter(edges, torch.tensor(-1.0)), torch.nextafter(edges, torch.tensor(2.0))]).flatten()
+        gen = torch.Generator().manual_seed(71)
+        pick = lambda: near[torch.randint(0, near.numel(), (2, 12), generator=gen)]      # noqa: E731
+        lo_x, lo_y, hi_x, hi_y = pick(), pick(), pick(), pick()
+        edge_boxes = torch.stack([lo_x, lo_y, torch.maximum(lo_x, hi_x), torch.maximum(lo_y, hi_y)], dim=-1).clamp(0, 0.95)
+        edge_boxes[1, 0] = torch.tensor([0.5, 0.5, 0.2, 0.9])          # x_max < x_min: nothing visible
+        edge_boxes[1, 1] = torch.tensor([-0.2, 0.3, 0.4, 0.3])         # below the first edge: cell 0
+        data.update(edge_boxes=edge_boxes.numpy(), edge_mask_g10=get_combine_masks(edge_boxes, 10).reshape(2, 1, 12, 100).numpy())
+        name = "g8_dlct_encoder%s.npz" % ("_trig" if trig else "")
+        np.savez_compressed(os.path.join(out_dir, name), **data)
+        print("wrote %s  (visible region->grid cells: %d of %d)" % (name, int((~r2g).sum()), r2g.numel()))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reference", default="/root/reference")
@@ -336,6 +433,8 @@ def main():
         g6_decode_caption(ref, HERE)
     if on("g7"):
         g7_reference_checkpoint(ref, HERE)
+    if on("g8"):
+        g8_dlct_encoder(ref, HERE)
     if on("g2"):
         for v in VARIANTS:
             g2_full(ref, HERE, v)

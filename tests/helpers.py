@@ -50,6 +50,26 @@ def full_case(variant, B, ragged=False):
     return cfg, vocab, sd, feats, boxes
 
 
+DLCT_TINY = dict(B=3, n_regions=7, grid=3, d_region=32, d_grid=24, d_model=64, heads=4, d_kv=16, d_ff=128, layers=2)
+DLCT_FULL = dict(B=4, n_regions=50, grid=7, d_region=2048, d_grid=1024, d_model=512, heads=8, d_kv=64, d_ff=2048, layers=3)
+
+
+def dlct_case(trig, shape=None, input_seed=61):
+    """(embedding cfg, encoder cfg, embedding weights, encoder weights, inputs) of the G8 fixtures (``shape=None``)
+    or of a larger case with the same generators."""
+    from openviic_amd.builders import build_encoder, build_vision_embedding
+    from openviic_amd.config import dual_collaborative_config
+    from openviic_amd.utils.synthetic import synthetic_dual_inputs
+    t = shape or DLCT_TINY
+    emb_cfg, enc_cfg = dual_collaborative_config(d_region=t["d_region"], d_grid=t["d_grid"], d_model=t["d_model"],
+                                                 heads=t["heads"], d_kv=t["d_kv"], d_ff=t["d_ff"], layers=t["layers"],
+                                                 trignometric_embedding=trig)
+    emb_sd = synthetic_state_dict(build_vision_embedding(emb_cfg).state_dict(), seed=51, mode="generic")
+    enc_sd = synthetic_state_dict(build_encoder(enc_cfg).state_dict(), seed=52, mode="generic")
+    inputs = synthetic_dual_inputs(t["B"], t["n_regions"], t["grid"], t["d_region"], t["d_grid"], seed=input_seed)
+    return emb_cfg, enc_cfg, emb_sd, enc_sd, inputs
+
+
 def teacher_tokens(B, T, V, seed, with_pad=True):
     g = torch.Generator().manual_seed(seed + 77)
     tok = torch.randint(4, V, (B, T), generator=g)

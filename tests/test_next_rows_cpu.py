@@ -67,3 +67,40 @@ def test_feature_files_collate_like_the_reference(tmp_path):
     npz = str(tmp_path / "9.npz")
     np.savez(npz, region_features=np.ones((2, 8), np.float32))
     assert load_feature_file(npz)["region_features"].shape == (2, 8)
+
+
+# ---- dual-collaborative encoder: host-side logic (no device work) --------------------------------------------
+
+def test_grid_visibility_mask_matches_reference_cell_lookup():
+    """The vectorised mask of the product against the reference's per-box loops (G8 vectors: coordinates one ulp
+    either side of the cell edges, inverted boxes, boxes below the first edge, the tiny encoder case)."""
+    import numpy as np
+    from helpers import golden
+    from openviic_amd.modules import grid_visibility_mask
+    g = golden("g8_dlct_encoder.npz")
+    np.testing.assert_array_equal(grid_visibility_mask(torch.from_numpy(g["edge_boxes"]), 10).numpy(), g["edge_mask_g10"])
+    n = g["region_boxes"].shape[1]
+    r2g = grid_visibility_mask(torch.from_numpy(g["region_boxes"]), 3).numpy()
+    np.testing.assert_array_equal(r2g, g["region2all_mask"][..., n:])
+    np.testing.assert_array_equal(np.swapaxes(r2g, 2, 3), g["grid2all_mask"][..., :n])
+
+
+def test_dual_collaborative_modules_register_and_match_reference_state_dict_surface():
+    from openviic_amd.builders import META_ENCODER, META_VISION_EMBEDDING, build_encoder, build_vision_embedding
+    from openviic_amd.config import dual_collaborative_config
+    emb_cfg, enc_cfg = dual_collaborative_config(d_region=32, d_grid=24, d_model=64, heads=4, d_kv=16, d_ff=128, layers=2)
+    for name in ("DualFeatureEmbedding", "GeometricDualFeatureEmbedding"):
+        assert META_VISION_EMBEDDING.get(name).__name__ == name
+    assert META_ENCODER.get("DualCollaborativeLevelEncoder").__name__ == "DualCollaborativeLevelEncoder"
+    emb, enc = build_vision_embedding(emb_cfg), build_encoder(enc_cfg)
+    assert sorted(emb.state_dict()) == ["grid_proj.bias", "grid_proj.weight", "region_proj.bias", "region_proj.weight"]
+    keys = set(enc.state_dict())
+    # key surface of the reference class (encoders.py:116-144): 4 layer stacks, two stream norms, per-head fc_gs
+    for stack in ("layers_region", "layers_grid", "region2grid", "grid2region"):
+        for i in range(2):
+            for leaf in ("mhatt.attention.fc_q.weight", "mhatt.layer_norm.bias", "pwff.fc1.weight", "pwff.fc2.bias",
+                         "pwff.layer_norm.weight"):
+                assert "%s.%d.%s" % (stack, i, leaf) in keys
+    assert {"layer_norm_region.weight", "layer_norm_grid.bias", "fc_gs.3.weight", "fc_gs.0.bias"} <= keys
+    assert len(keys) == 4 + 2 * 4 + 4 * 2 * 16
+    assert enc.state_dict()["fc_gs.0.weight"].shape == (1, 4)

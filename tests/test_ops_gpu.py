@@ -263,3 +263,55 @@ def test_beam_select_massive_ties_take_lowest_indices():
     np.testing.assert_array_equal(chosen.cpu().numpy(), want_idx.numpy())
     np.testing.assert_array_equal(score.cpu().numpy(), want_val.numpy())
     assert chosen[0].tolist() == [0, 1, 2, 3, 4] and chosen[1].tolist() == [2 * V + i for i in range(5)]
+
+
+# ---- dual-collaborative (DLCT) embedding + encoder ---------------------------------------------------------
+
+def _dlct_device_modules(emb_cfg, enc_cfg, emb_sd, enc_sd):
+    from openviic_amd.builders import build_encoder, build_vision_embedding
+    emb, enc = build_vision_embedding(emb_cfg).eval(), build_encoder(enc_cfg).eval()
+    emb.load_state_dict(emb_sd)
+    enc.load_state_dict(enc_sd)
+    return emb.to(DEV), enc.to(DEV)
+
+
+def _dlct_run(emb, enc, inputs):
+    region, region_boxes, grid, grid_boxes = (t.to(DEV) for t in inputs)
+    (rf, rm), (gf, gm), (r2a, g2a) = emb(region, region_boxes, grid, grid_boxes)
+    out, mask = enc(rf, region_boxes, rm, r2a, gf, grid_boxes, gm, g2a)
+    return rf, gf, rm, gm, r2a, g2a, out, mask
+
+
+@pytest.mark.parametrize("trig", [False, True])
+def test_dlct_encoder_against_reference_golden(trig):
+    """G8: the reference's own sub-modules composed with the three documented mask repairs."""
+    from helpers import dlct_case
+    g = golden("g8_dlct_encoder%s.npz" % ("_trig" if trig else ""))
+    emb_cfg, enc_cfg, emb_sd, enc_sd, inputs = dlct_case(trig)
+    emb, enc = _dlct_device_modules(emb_cfg, enc_cfg, emb_sd, enc_sd)
+    rf, gf, rm, gm, r2a, g2a, out, mask = _dlct_run(emb, enc, inputs)
+    for got, name in ((rm, "region_mask"), (gm, "grid_mask"), (r2a, "region2all_mask"), (g2a, "grid2all_mask"),
+                      (mask, "padding_mask")):
+        np.testing.assert_array_equal(got.cpu().numpy(), g[name], err_msg=name)
+    _close(rf, torch.from_numpy(g["region_embedded"]), what="region projection")
+    _close(gf, torch.from_numpy(g["grid_embedded"]), what="grid projection")
+    _close(out, torch.from_numpy(g["out"]), tol=5e-5, what="DLCT encoder output")
+    n = g["region_mask"].shape[-1]
+    assert (out[:, :n][rm[:, 0, 0]] == 0).all()          # padded region rows are cleared, as the repair says
+
+
+@pytest.mark.parametrize("trig", [False, True])
+def test_dlct_encoder_full_size_against_oracle(trig):
+    """d=512, 50 regions + 7x7 grid cells (nk = 99), 3 layers, B=4, ragged regions."""
+    from helpers import DLCT_FULL, dlct_case
+    from oracle.dlct import OracleDualEncoder
+    emb_cfg, enc_cfg, emb_sd, enc_sd, inputs = dlct_case(trig, DLCT_FULL, input_seed=17)
+    orc = OracleDualEncoder(enc_cfg, emb_sd, enc_sd)
+    region, region_boxes, grid, grid_boxes = inputs
+    (orf, orm), (ogf, ogm), (or2a, og2a) = orc.embed(region, region_boxes, grid, grid_boxes)
+    want, want_mask = orc.encode(orf, region_boxes, orm, or2a, ogf, grid_boxes, ogm, og2a)
+    emb, enc = _dlct_device_modules(emb_cfg, enc_cfg, emb_sd, enc_sd)
+    rf, gf, rm, gm, r2a, g2a, out, mask = _dlct_run(emb, enc, inputs)
+    assert torch.equal(r2a.cpu(), or2a) and torch.equal(g2a.cpu(), og2a) and torch.equal(mask.cpu(), want_mask)
+    assert orm.any() and not orm.all()
+    _close(out, want, tol=1e-4, what="DLCT encoder (full size)")

@@ -110,3 +110,39 @@ def test_full_size_teacher_forced_sample():
     logp = orc.forward(feats, torch.from_numpy(g["fwd_tokens"]))
     np.testing.assert_allclose(logp[:, :, ::97].numpy(), g["fwd_sample"], rtol=1e-5, atol=1e-5)
     np.testing.assert_array_equal(logp.argmax(-1).numpy(), g["fwd_argmax"])
+
+
+# ---- dual-collaborative (DLCT) embedding + encoder: oracle/dlct.py against G8 ------------------------------
+
+@pytest.mark.parametrize("trig", [False, True])
+def test_dlct_oracle_against_reference_submodule_composition(trig):
+    from helpers import dlct_case
+    from oracle.dlct import OracleDualEncoder
+    g = golden("g8_dlct_encoder%s.npz" % ("_trig" if trig else ""))
+    emb_cfg, enc_cfg, emb_sd, enc_sd, (region, region_boxes, grid, grid_boxes) = dlct_case(trig)
+    for name, value in (("region_features", region), ("region_boxes", region_boxes), ("grid_features", grid),
+                        ("grid_boxes", grid_boxes)):
+        np.testing.assert_array_equal(value.numpy(), g[name], err_msg=name)
+    orc = OracleDualEncoder(enc_cfg, emb_sd, enc_sd)
+    (rf, rm), (gf, gm), (r2a, g2a) = orc.embed(region, region_boxes, grid, grid_boxes)
+    np.testing.assert_array_equal(rm.numpy(), g["region_mask"])
+    np.testing.assert_array_equal(gm.numpy(), g["grid_mask"])
+    np.testing.assert_array_equal(r2a.numpy(), g["region2all_mask"])
+    np.testing.assert_array_equal(g2a.numpy(), g["grid2all_mask"])
+    np.testing.assert_allclose(rf.numpy(), g["region_embedded"], rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(gf.numpy(), g["grid_embedded"], rtol=1e-5, atol=2e-6)
+    orc.trace = {}
+    out, mask = orc.encode(rf, region_boxes, rm, r2a, gf, grid_boxes, gm, g2a)
+    assert np.isfinite(g["out"]).all()
+    np.testing.assert_array_equal(mask.numpy(), g["padding_mask"])
+    for name in ("geometry_weights", "layer0_region", "layer0_grid", "layer1_region", "layer1_grid"):
+        np.testing.assert_allclose(orc.trace[name].numpy(), g[name], rtol=1e-5, atol=5e-6, err_msg=name)
+    np.testing.assert_allclose(out.numpy(), g["out"], rtol=1e-5, atol=5e-6)
+
+
+def test_dlct_grid_cell_lookup_next_to_cell_edges():
+    """float32 coordinates one ulp either side of the (float64) cell edges, inverted and out-of-range boxes."""
+    from oracle.dlct import grid_visibility_mask
+    g = golden("g8_dlct_encoder.npz")
+    mask = grid_visibility_mask(torch.from_numpy(g["edge_boxes"]), 10)
+    np.testing.assert_array_equal(mask.numpy(), g["edge_mask_g10"])

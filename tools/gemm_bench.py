@@ -57,9 +57,13 @@ def main():
         b = torch.randn(N, device=dev)
         times = []
         y = torch.empty(M, N, device=dev)
+        ref_y = torch.addmm(b, x, w.t())
         for t in range(len(TILINGS)):
             lib.ovc_debug_force_gemm_tiling(t)
             times.append(time_native(lib, x, w, b, y))
+            err = (y - ref_y).abs().max().item()
+            if err > 2e-3:
+                print("  !! tiling %s differs from torch.addmm by %.3e" % (TILINGS[t], err))
         lib.ovc_debug_force_gemm_tiling(-1)
         auto = time_native(lib, x, w, b, y)
         ref = timeit(lambda: torch.addmm(b, x, w.t()))
