@@ -186,8 +186,7 @@ class CaptionEngine:
 
     # -- calls --------------------------------------------------------------------------------
     def encode(self, features, boxes=None):
-        features = self._features(features, "features")
-        boxes = None if boxes is None else self._features(boxes, "boxes")
+        features, boxes = self._checked_inputs(features, boxes)
         B, N = features.shape[:2]
         ws, need = self._get_workspace(B, N, 1, False)
         d = self.desc
@@ -199,9 +198,21 @@ class CaptionEngine:
                                   native.stream_handle()), "ovc_encode")
         return out, mask.view(torch.bool)[:, None, None, :]
 
-    def beam_search(self, features, boxes, batch_size, beam_size, out_size=1, return_probs=False):
+    def _checked_inputs(self, features, boxes):
+        """The kernels index with the model's strides: shapes are verified here, on the host, before any launch."""
         features = self._features(features, "features")
         boxes = None if boxes is None else self._features(boxes, "boxes")
+        if features.dim() != 3 or features.shape[2] != self.desc.d_feat:
+            raise native.OvcError("features must be (B, N, {}); got {}".format(self.desc.d_feat, tuple(features.shape)))
+        if boxes is not None and tuple(boxes.shape) != (features.shape[0], features.shape[1], 4):
+            raise native.OvcError("boxes must be {}; got {}".format((features.shape[0], features.shape[1], 4),
+                                                                    tuple(boxes.shape)))
+        if self.desc.enc_kind == native.ENC_GEOMETRIC and boxes is None:
+            raise native.OvcError("the geometric encoder needs region boxes")
+        return features, boxes
+
+    def beam_search(self, features, boxes, batch_size, beam_size, out_size=1, return_probs=False):
+        features, boxes = self._checked_inputs(features, boxes)
         B, N = features.shape[:2]
         if B != batch_size:
             raise native.OvcError("batch_size={} but features hold {} images".format(batch_size, B))

@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import (FULL, TINY_SHAPE, VARIANTS, assert_ids_match_where_decided, batch, device_model, full_case,
+from helpers import (FULL, TINY, TINY_SHAPE, VARIANTS, assert_ids_match_where_decided, batch, device_model, full_case,
                      golden, teacher_tokens, tiny_case)
 from oracle.captioner import OracleCaptioner
 
@@ -234,3 +234,65 @@ def test_hipgraph_replay_matches_plain_launches():
         assert torch.equal(wi, gi) and torch.equal(wl, gl)
     assert not torch.equal(got[0][0], got[1][0])                          # different images, different captions
     assert torch.equal(got[0][0], got[3][0])
+
+
+# ---- edges of the domain -----------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("B,N,k,out_size", [(1, 1, 1, 1), (1, 7, 8, 8), (2, 3, 2, 2), (5, 7, 4, 1), (3, 7, 5, 3)])
+def test_small_and_extreme_shapes_against_oracle(B, N, k, out_size):
+    """One image, one region, beam 1 up to the ABI's maximum beam (8), out_size < k."""
+    from openviic_amd.utils.synthetic import synthetic_features
+    cfg, vocab, sd, _, _ = tiny_case("standard_transformer")
+    feats = synthetic_features(B, N, TINY["d_feature"], seed=40 + B + N)
+    orc = OracleCaptioner(cfg, sd, len(vocab), vocab.max_caption_length)
+    rec = {}
+    want_ids, want_logp = orc.beam_search(feats, k, out_size=out_size, record=rec)
+    model = device_model(cfg, vocab, sd)
+    with torch.no_grad():
+        ids, logp = model.beam_search(batch(feats), batch_size=B, beam_size=k, out_size=out_size)
+    assert ids.shape == want_ids.shape and logp.shape == want_logp.shape
+    np.testing.assert_array_equal(ids.cpu().numpy(), want_ids.numpy())
+    _logp_close(logp.cpu().numpy(), want_logp.numpy(), "B=%d N=%d k=%d" % (B, N, k))
+
+
+def test_concurrent_streams_give_the_single_stream_result():
+    """bench.py's configuration: consecutive batches alternate over three HIP streams, each with its own engine
+    workspace and its own captured graph; every batch must decode exactly as it does alone."""
+    cfg, vocab, sd, feats, _ = full_case("standard_transformer", 48)
+    model = device_model(cfg, vocab, sd)
+    chunks = [feats[i * 16:(i + 1) * 16].cuda() for i in range(3)]
+    with torch.no_grad():
+        alone = [model.beam_search(batch(c), batch_size=16, beam_size=5) for c in chunks]
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream() for _ in range(3)]
+    rounds = []
+    with torch.no_grad():
+        for _ in range(4):                                  # plain, capture, then replayed graphs, all overlapping
+            outs = []
+            for s, c in zip(streams, chunks):
+                with torch.cuda.stream(s):
+                    outs.append(model.beam_search(batch(c), batch_size=16, beam_size=5))
+            rounds.append(outs)
+    torch.cuda.synchronize()
+    for outs in rounds:
+        for (ids, logp), (want_ids, want_logp) in zip(outs, alone):
+            assert torch.equal(ids, want_ids) and torch.equal(logp, want_logp)
+
+
+def test_invalid_requests_fail_loudly():
+    from openviic_amd import native
+    cfg, vocab, sd, feats, _ = tiny_case("standard_transformer")
+    model = device_model(cfg, vocab, sd)
+    with torch.no_grad():
+        with pytest.raises(native.OvcError):                # beam wider than the ABI's OVC_MAX_BEAM
+            model.beam_search(batch(feats), batch_size=feats.shape[0], beam_size=9)
+        with pytest.raises(native.OvcError):                # out_size > beam_size
+            model.beam_search(batch(feats), batch_size=feats.shape[0], beam_size=2, out_size=3)
+        with pytest.raises(native.OvcError):                # batch_size disagrees with the features
+            model.beam_search(batch(feats), batch_size=feats.shape[0] + 1, beam_size=2)
+        with pytest.raises(native.OvcError):                # host tensor: there is no CPU path
+            model.beam_search(batch(feats, device="cpu"), batch_size=feats.shape[0], beam_size=2)
+        with pytest.raises(native.OvcError):                # feature width differs from the projection's
+            model.beam_search(batch(feats[:, :, :16].contiguous()), batch_size=feats.shape[0], beam_size=2)
+        ids, _ = model.beam_search(batch(feats), batch_size=feats.shape[0], beam_size=3)   # still usable afterwards
+    assert ids.shape == (feats.shape[0], TINY_SHAPE["T"])
