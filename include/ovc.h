@@ -210,13 +210,16 @@ const char* ovc_profile_kernel_name(int tiling);   /* "" past the last tiling */
 /* Measure every GEMM tiling on the shape y[M, nseg*seg_n] = x[M,K] W^T (nseg weight segments of
  * seg_n rows) and remember the fastest for this process; later ovc_linear / engine GEMMs of that
  * shape use it.  scratch: >= 4*(M*K + nseg*seg_n*K + M*nseg*seg_n) + 64 bytes of device memory
- * (contents are used as operands).  SYNCHRONISES the stream -- set-up time only. */
+ * (contents are used as operands).  For single-segment shapes with few output tiles the 2- and 4-way
+ * K splits (partial products summed by the consuming LayerNorm, engine only) are measured as well when
+ * the scratch has room for 2x / 4x the output.  SYNCHRONISES the stream -- set-up time only. */
 int ovc_gemm_tune(int M, int seg_n, int nseg, int K, void* scratch, size_t scratch_bytes,
                   ovc_stream stream);
 
-/* Read / preset the remembered tiling of a shape (-1 = not tuned): lets a host persist tuning results. */
+/* Read / preset the remembered choice of a shape (-1 = not tuned): lets a host persist tuning results.
+ * The value is  tiling | split << 8 | split_tiling << 16  (split 1: no K split, split_tiling 0). */
 int ovc_gemm_tuned_get(int M, int seg_n, int nseg, int K);
-int ovc_gemm_tuned_set(int M, int seg_n, int nseg, int K, int tiling);
+int ovc_gemm_tuned_set(int M, int seg_n, int nseg, int K, int code);
 
 /* Tuning hook (tools/gemm_bench.py): force GEMM tiling 0..6 (see csrc/gemm.hip) for every
  * following ovc_linear / engine GEMM in this process; -1 restores the automatic choice. */

@@ -49,6 +49,9 @@ struct GemmArgs {
     int ldr;
     int res_mod;         // > 0: the residual has res_mod rows and row m reads row m % res_mod (broadcast over stacked blocks)
     int act;             // 0 none, 1 relu
+    int ksplit;          // > 1: K is cut into ksplit equal slices, slice s writes its raw partial product (no bias /
+                         // activation / residual) to seg[0].C + s * part_stride; the consumer sums the slices in order
+    long part_stride;    // floats between two partial outputs
     GemmSegment seg[OVC_MAX_SEGMENTS];
 };
 
@@ -57,6 +60,14 @@ int ovc_gemm_launch(const GemmArgs& args, hipStream_t stream);
 // Same launch with kernel-scoped events (dispatch begin / end timestamps) for profiling.
 int ovc_gemm_launch_timed(const GemmArgs& args, hipStream_t stream, hipEvent_t start, hipEvent_t stop);
 int ovc_gemm_pick_tiling(const GemmArgs& args);      // index of the tiling ovc_gemm_launch will use
+// K split the tuner measured as fastest for a single-segment M x N x K product whose consumer can sum partial
+// outputs (1 = none; also for shapes that were never tuned).  At most kMaxKSplit.
+constexpr int kMaxKSplit = 4;
+int ovc_gemm_split_for(int M, int N, int K);
+// LayerNorm(sum_s parts[s] + bias + residual): the consumer side of a K-split GEMM (rowops.hip).
+int ovc_layer_norm_parts(const float* parts, int nparts, long part_stride, const float* bias, const float* residual,
+                         const float* gamma, const float* beta, const uint8_t* zero_rows, float eps, float* y,
+                         int rows, int d, hipStream_t stream);
 const char* ovc_gemm_tiling_name(int tiling);        // kernel name as rocprofv3 prints it
 
 // ---- decode-time attention (attention.hip) -------------------------------------------------

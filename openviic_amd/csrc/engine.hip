@@ -91,6 +91,7 @@ struct Workspace {
     // decoder
     float* x; float* x1; float* x2; float* y; float* q; float* att; float* ff; float* info; float* gate;
     float* enc_att; float* alpha; float* mixed; float* ymesh;
+    float* part;                                  // [kMaxKSplit][R][d] partial outputs of K-split projections
     float* kc; float* vc;                         // [L][T][R][h*dk|h*dv]
     uint8_t* padflag;                             // [T][R]
     float* logits;                                // [R][V]
@@ -141,6 +142,7 @@ Workspace carve(const ovc_model* m, void* base, int B, int N, int k, int return_
     w.info = a.take<float>(R * d); w.gate = a.take<float>(R * d);
     w.enc_att = a.take<float>(lv * R * d); w.alpha = a.take<float>(lv * R * d); w.mixed = a.take<float>(R * d);
     w.ymesh = a.take<float>(lv > 1 ? lv * R * d : 0);
+    w.part = a.take<float>(kMaxKSplit * R * d);
     w.kc = a.take<float>(L * T * R * hk);
     w.vc = a.take<float>(L * T * R * hv);
     w.padflag = a.take<uint8_t>(T * R);
@@ -231,6 +233,25 @@ struct Engine {
         return gemm(a);
     }
 
+    // out = LayerNorm(x W^T + b + residual), rows flagged in zero_rows cleared.  Shapes for which the tuner found a
+    // K split faster (the M = B*k projections back to d_model, K = d_ff above all) run the GEMM as `split` slices
+    // writing partial products; the LayerNorm kernel sums them in slice order and applies bias and residual.
+    int linear_ln(const float* x, int K, const ovc_lin& l, const float* residual, const ovc_norm& ln,
+                  const uint8_t* zero_rows, float* y_tmp, float* part, float* out, int M) {
+        const int d = m->d_model;
+        const int split = part ? ovc_gemm_split_for(M, d, K) : 1;
+        if (split <= 1) {
+            TRY(linear(x, K, l, residual, y_tmp, M, d, 0));
+            return ovc_layer_norm(y_tmp, nullptr, ln.g, ln.b, nullptr, 0, zero_rows, m->ln_eps, out, M, d, stream);
+        }
+        GemmArgs a{};
+        a.A1 = x; a.lda1 = K; a.K1 = K; a.M = M; a.seg_n = d; a.nseg = 1; a.ldc = d;
+        a.ksplit = split; a.part_stride = (long)M * d;
+        a.seg[0] = GemmSegment{l.w, nullptr, part};
+        TRY(gemm(a));
+        return ovc_layer_norm_parts(part, split, a.part_stride, l.b, residual, ln.g, ln.b, zero_rows, m->ln_eps, out, M, d, stream);
+    }
+
     // AoA gate (attentions.py:311-315): out = W_i [q; x] * sigmoid(W_g [q; x]), one two-segment GEMM.
     int aoa(const ovc_mha& w, const float* queries, float* x, float* info, float* gate, int M) {
         if (!w.aoa_i.w) return OVC_OK;
@@ -251,11 +272,9 @@ struct Engine {
         return ovc_sigmoid_gate(info, gate, x, (long)M * d, stream);
     }
 
-    int ffn(const ovc_ffn& w, const float* x, float* ff, float* y, float* out, const uint8_t* zero_rows, int M) {
-        const int d = m->d_model;
-        TRY(linear(x, d, w.fc1, nullptr, ff, M, m->d_ff, 1));
-        TRY(linear(ff, m->d_ff, w.fc2, x, y, M, d, 0));
-        return ovc_layer_norm(y, nullptr, w.ln.g, w.ln.b, nullptr, 0, zero_rows, m->ln_eps, out, M, d, stream);
+    int ffn(const ovc_ffn& w, const float* x, float* ff, float* y, float* part, float* out, const uint8_t* zero_rows, int M) {
+        TRY(linear(x, m->d_model, w.fc1, nullptr, ff, M, m->d_ff, 1));
+        return linear_ln(ff, m->d_ff, w.fc2, x, w.ln, zero_rows, y, part, out, M);
     }
 };
 
@@ -302,7 +321,7 @@ int run_encoder_layers(Engine& e, Workspace& w, int B, int N) {
         // layer output: straight into the level slot (multilevel) or the ping-pong buffer
         float* out = m->enc_kind == OVC_ENC_MULTILEVEL ? w.enc_levels + (size_t)l * BN * d
                                                        : (l == m->n_enc - 1 ? w.enc_levels : x);
-        TRY(e.ffn(m->enc[l].ffn, x1, w.eff, w.ey, out, w.enc_mask, BN));
+        TRY(e.ffn(m->enc[l].ffn, x1, w.eff, w.ey, nullptr, out, w.enc_mask, BN));
         x = out;
     }
     return OVC_OK;
@@ -367,8 +386,7 @@ int run_decode_step(Engine& e, Workspace& w, int B, int N, int k, int t, int ret
         sa.anc = w.anc[cur]; sa.anc_ld = T; sa.padflag = w.padflag; sa.pad_ld = R; sa.t = t;
         sa.h = m->heads; sa.dk = m->d_k; sa.dv = m->d_v; sa.out = w.att; sa.ldo = hv;
         TRY(ovc_decode_self_attention(sa, rows, s));
-        TRY(e.linear(w.att, hv, dl.self_att.o, x, w.y, rows, d, 0));
-        TRY(ovc_layer_norm(w.y, nullptr, dl.self_att.ln.g, dl.self_att.ln.b, nullptr, 0, nullptr, m->ln_eps, w.x1, rows, d, s));
+        TRY(e.linear_ln(w.att, hv, dl.self_att.o, x, dl.self_att.ln, nullptr, w.y, w.part, w.x1, rows));
         TRY(e.aoa(dl.self_att, x, w.x1, w.info, w.gate, rows));
 
         // ---- cross-attention: the image's beams share its projected encoder keys/values -----------
@@ -411,12 +429,11 @@ int run_decode_step(Engine& e, Workspace& w, int B, int N, int k, int t, int ret
             TRY(ovc_meshed_mix(w.alpha, w.enc_att, lv, (long)nrd, sqrtf((float)lv), w.mixed, s));
             ffn_in = w.mixed;
         } else {
-            TRY(e.linear(w.att, hv, dl.cross_att.o, w.x1, w.y, rows, d, 0));
-            TRY(ovc_layer_norm(w.y, nullptr, dl.cross_att.ln.g, dl.cross_att.ln.b, nullptr, 0, nullptr, m->ln_eps, w.x2, rows, d, s));
+            TRY(e.linear_ln(w.att, hv, dl.cross_att.o, w.x1, dl.cross_att.ln, nullptr, w.y, w.part, w.x2, rows));
             TRY(e.aoa(dl.cross_att, w.x1, w.x2, w.info, w.gate, rows));
             ffn_in = w.x2;
         }
-        TRY(e.ffn(dl.ffn, ffn_in, w.ff, w.y, w.x, padflag_t, rows));
+        TRY(e.ffn(dl.ffn, ffn_in, w.ff, w.y, w.part, w.x, padflag_t, rows));
         x = w.x;
     }
 

@@ -97,7 +97,12 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma(GemmArgs p, int tiles_m, in
 
     const float* __restrict__ W = p.seg[seg].W;
     const int K = p.K1 + p.K2;
-    const int nkt = (K + BK - 1) / BK;
+    // Cross-workgroup K split (gridDim.y slices): this workgroup covers [kbase, kbase + K / gridDim.y) and writes a
+    // raw partial tile.  It halves / quarters the operand bytes a CU pulls through its L2 port for the M = 1280
+    // decode shapes, whose 32x32 tiles are bound by that port rather than by the matrix cores.
+    const int kslice = gridDim.y > 1 ? K / (int)gridDim.y : K;
+    const int kbase = (int)blockIdx.y * kslice;
+    const int nkt = (kslice + BK - 1) / BK;
 
     constexpr int kBufFloats = (BM + BN) * LDT;   // one buffer: A tile then B tile
 
@@ -132,7 +137,7 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma(GemmArgs p, int tiles_m, in
         for (int i = 0; i < Cfg::kLoadB; ++i) off_w[i] = ((n0 + tid / kVecPerRow + i * kRowsPerPass) * K + kq * 4) * 4;
     }
     auto load_tile = [&](int kt) {
-        const int k0 = kt * BK;
+        const int k0 = kbase + kt * BK;
         const bool second = k0 >= p.K1;                       // uniform: which of A1 | A2 this K tile comes from
         if (k_tail) {
             const int kq = tid % kVecPerRow;
@@ -257,7 +262,7 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma(GemmArgs p, int tiles_m, in
     // column) and a scalar row offset per accumulator register; rows past M fall outside the descriptor and
     // are dropped by the hardware, columns past seg_n get an out-of-range offset.
     const float* __restrict__ bias = p.seg[seg].bias;
-    float* __restrict__ C = p.seg[seg].C;
+    float* __restrict__ C = p.seg[seg].C + (size_t)blockIdx.y * p.part_stride;
     const int half = lane >> 5;
     const bool has_res = p.R != nullptr;                          // uniform
     const __amdgpu_buffer_rsrc_t rsrc_c = __builtin_amdgcn_make_buffer_rsrc(C, 0, p.M * p.ldc * 4, 0x00020000);
@@ -323,11 +328,12 @@ int launch_config(const GemmArgs& a, hipStream_t stream) {
     // A panel larger than ~3 MB cannot stay in a 4 MB L2: sweep it in super-rows of 8 M tiles
     const size_t a_bytes = sizeof(float) * (size_t)a.M * (a.K1 + a.K2);
     const int group_m = a_bytes <= (size_t)3 << 20 ? tiles_m : (tiles_m < 8 ? tiles_m : 8);
+    const dim3 grid3(grid, a.ksplit > 1 ? a.ksplit : 1);
     if (g_launch_start && g_launch_stop)
-        hipExtLaunchKernelGGL((gemm_f32_mfma<BM, BN, WM, WN, WK, BK>), dim3(grid), dim3(256), (uint32_t)lds_bytes, stream,
+        hipExtLaunchKernelGGL((gemm_f32_mfma<BM, BN, WM, WN, WK, BK>), grid3, dim3(256), (uint32_t)lds_bytes, stream,
                               g_launch_start, g_launch_stop, 0, a, tiles_m, tiles_n, group_m);
     else
-        hipLaunchKernelGGL((gemm_f32_mfma<BM, BN, WM, WN, WK, BK>), dim3(grid), dim3(256), lds_bytes, stream, a, tiles_m, tiles_n, group_m);
+        hipLaunchKernelGGL((gemm_f32_mfma<BM, BN, WM, WN, WK, BK>), grid3, dim3(256), lds_bytes, stream, a, tiles_m, tiles_n, group_m);
     OVC_RETURN_IF_LAUNCH_FAILED();
     return OVC_OK;
 }
@@ -351,15 +357,22 @@ constexpr int kNumTilings = sizeof(kTilings) / sizeof(kTilings[0]);
 
 int g_forced_tiling = -1;   // tuning hook (ovc_debug_force_gemm_tiling); -1 = automatic
 
-// Shapes measured by ovc_gemm_tune: (M, seg_n, nseg, K) -> fastest tiling on this device.
-struct TunedShape { int M, seg_n, nseg, K, tiling; };
+// Shapes measured by ovc_gemm_tune: (M, seg_n, nseg, K) -> fastest tiling on this device, and (single-segment
+// shapes) the fastest K split with its tiling for callers whose consumer sums partial outputs.
+struct TunedShape { int M, seg_n, nseg, K, tiling, split, split_tiling; };
 std::vector<TunedShape> g_tuned;
 
-int tuned_lookup(const GemmArgs& a) {
-    const int K = a.K1 + a.K2;
+const TunedShape* tuned_find(int M, int seg_n, int nseg, int K) {
     for (const TunedShape& t : g_tuned)
-        if (t.M == a.M && t.seg_n == a.seg_n && t.nseg == a.nseg && t.K == K) return t.tiling;
-    return -1;
+        if (t.M == M && t.seg_n == seg_n && t.nseg == nseg && t.K == K) return &t;
+    return nullptr;
+}
+
+int tuned_lookup(const GemmArgs& a) {
+    const TunedShape* t = tuned_find(a.M, a.seg_n, a.nseg, a.K1 + a.K2);
+    if (!t) return -1;
+    if (a.ksplit > 1) return t->split == a.ksplit ? t->split_tiling : -1;
+    return t->tiling;
 }
 
 // Predicted time of a tiling in MFMA-issue units (one unit = one v_mfma_f32_32x32x2_f32 slot of a
@@ -400,6 +413,7 @@ const char* ovc_gemm_tiling_name(int tiling) {
 static bool tiling_fits(const GemmArgs& a, int t) {
     if (a.nseg > 1 && a.seg_n % kTilings[t].bn) return false;
     if (a.K2 > 0 && a.K1 % kTilings[t].bk) return false;
+    if (a.ksplit > 1 && (a.K1 / a.ksplit) % kTilings[t].bk) return false;     // a slice is a whole number of K tiles
     return true;
 }
 
@@ -431,6 +445,10 @@ int ovc_gemm_launch(const GemmArgs& a, hipStream_t stream) {
     if (!ovc_aligned16(a.A1) || (a.K2 && !ovc_aligned16(a.A2))) return OVC_EINVAL;
     if (a.R && a.nseg != 1) return OVC_EINVAL;
     if (a.K2 > 0 && (a.K1 % 32)) return OVC_EINVAL;      // the A1|A2 seam must fall on a K-tile boundary
+    if (a.ksplit > 1) {                                  // raw partial products: see GemmArgs::ksplit
+        if (a.ksplit > kMaxKSplit || a.nseg != 1 || a.K2 || a.R || a.act || a.seg[0].bias) return OVC_EINVAL;
+        if (a.K1 % (a.ksplit * 32) || a.part_stride < (long)a.M * a.ldc) return OVC_EINVAL;
+    }
     for (int s = 0; s < a.nseg; ++s)
         if (!a.seg[s].W || !a.seg[s].C || !ovc_aligned16(a.seg[s].W)) return OVC_EINVAL;
     if (a.nseg > 1 && a.seg_n % 64) return OVC_EINVAL;   // a tile may not straddle two segments
@@ -472,43 +490,73 @@ extern "C" int ovc_gemm_tune(int M, int seg_n, int nseg, int K, void* scratch, s
     GemmArgs a{};
     a.A1 = A; a.lda1 = K; a.K1 = K; a.M = M; a.seg_n = seg_n; a.nseg = nseg; a.ldc = seg_n;
     for (int s = 0; s < nseg; ++s) a.seg[s] = GemmSegment{W + (size_t)s * seg_n * K, nullptr, C + (size_t)s * M * seg_n};
-    if (tuned_lookup(a) >= 0) return OVC_OK;
+    if (tuned_find(M, seg_n, nseg, K)) return OVC_OK;
     hipStream_t st = ovc_hip_stream(stream);
     hipEvent_t e0, e1;
     if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return OVC_ELAUNCH;
     const int saved = g_forced_tiling;
-    float best_ms = 1e30f;
-    int best = -1, rc = OVC_OK;
-    for (int t = 0; t < kNumTilings && rc == OVC_OK; ++t) {
-        if (nseg > 1 && seg_n % kTilings[t].bn) continue;
-        g_forced_tiling = t;
-        for (int i = 0; i < 2 && rc == OVC_OK; ++i) rc = ovc_gemm_launch(a, st);
-        (void)hipEventRecord(e0, st);
-        for (int i = 0; i < 6 && rc == OVC_OK; ++i) rc = ovc_gemm_launch(a, st);
-        (void)hipEventRecord(e1, st);
-        if (hipEventSynchronize(e1) != hipSuccess) rc = OVC_ELAUNCH;
+    int rc = OVC_OK;
+    // fastest tiling of `a` (plain or K-split), -1 when nothing fits
+    auto fastest = [&](const GemmArgs& g, float* best_ms) {
+        int best = -1;
+        *best_ms = 1e30f;
+        for (int t = 0; t < kNumTilings && rc == OVC_OK; ++t) {
+            if (!tiling_fits(g, t)) continue;
+            g_forced_tiling = t;
+            for (int i = 0; i < 2 && rc == OVC_OK; ++i) rc = ovc_gemm_launch(g, st);
+            (void)hipEventRecord(e0, st);
+            for (int i = 0; i < 6 && rc == OVC_OK; ++i) rc = ovc_gemm_launch(g, st);
+            (void)hipEventRecord(e1, st);
+            if (hipEventSynchronize(e1) != hipSuccess) rc = OVC_ELAUNCH;
+            float ms = 0.f;
+            if (rc == OVC_OK && hipEventElapsedTime(&ms, e0, e1) == hipSuccess && ms < *best_ms) { *best_ms = ms; best = t; }
+        }
+        return best;
+    };
+    float plain_ms = 0.f;
+    const int plain = fastest(a, &plain_ms);
+    // K splits for single-segment shapes, as far as the scratch holds the partial outputs; a split must beat the
+    // plain product by 5 % to be chosen (its consumer reads `split` times the output)
+    int split = 1, split_tiling = -1;
+    float split_ms = plain_ms * 0.95f;
+    // (only shapes with few output tiles can gain: with >= 1024 tiles of 64x64 the plain product already fills the chip)
+    const bool few_tiles = (long)((M + 63) / 64) * ((seg_n + 63) / 64) < 1024;
+    for (int s = 2; s <= kMaxKSplit && nseg == 1 && few_tiles && rc == OVC_OK; s *= 2) {
+        if (K % (s * 32) || (size_t)(C - A) + (size_t)s * nc > scratch_bytes / sizeof(float)) continue;
+        GemmArgs g = a;
+        g.ksplit = s; g.part_stride = (long)nc;
         float ms = 0.f;
-        if (rc == OVC_OK && hipEventElapsedTime(&ms, e0, e1) == hipSuccess && ms < best_ms) { best_ms = ms; best = t; }
+        const int t = fastest(g, &ms);
+        if (t >= 0 && ms < split_ms) { split_ms = ms; split = s; split_tiling = t; }
     }
     g_forced_tiling = saved;
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     if (rc != OVC_OK) return rc;
-    if (best >= 0) g_tuned.push_back(TunedShape{M, seg_n, nseg, K, best});
+    if (plain >= 0) g_tuned.push_back(TunedShape{M, seg_n, nseg, K, plain, split, split_tiling});
     return OVC_OK;
 }
 
+// Tuned entry as one integer: tiling | split << 8 | split_tiling << 16 (split 1 = no K split); -1 = not tuned.
 extern "C" int ovc_gemm_tuned_get(int M, int seg_n, int nseg, int K) {
-    for (const TunedShape& t : g_tuned)
-        if (t.M == M && t.seg_n == seg_n && t.nseg == nseg && t.K == K) return t.tiling;
-    return -1;
+    const TunedShape* t = tuned_find(M, seg_n, nseg, K);
+    return t ? (t->tiling | t->split << 8 | (t->split > 1 ? t->split_tiling : 0) << 16) : -1;
 }
 
-extern "C" int ovc_gemm_tuned_set(int M, int seg_n, int nseg, int K, int tiling) {
-    if (tiling < 0 || tiling >= kNumTilings || (nseg > 1 && seg_n % kTilings[tiling].bn)) return OVC_EINVAL;
+extern "C" int ovc_gemm_tuned_set(int M, int seg_n, int nseg, int K, int code) {
+    const int tiling = code & 0xff, split = (code >> 8) & 0xff, split_tiling = (code >> 16) & 0xff;
+    if (code < 0 || tiling >= kNumTilings || (nseg > 1 && seg_n % kTilings[tiling].bn)) return OVC_EINVAL;
+    if (split > 1 && (split > kMaxKSplit || nseg != 1 || K % (split * kTilings[split_tiling < kNumTilings ? split_tiling : 0].bk) ||
+                      split_tiling >= kNumTilings)) return OVC_EINVAL;
+    const TunedShape entry{M, seg_n, nseg, K, tiling, split > 1 ? split : 1, split > 1 ? split_tiling : -1};
     for (TunedShape& t : g_tuned)
-        if (t.M == M && t.seg_n == seg_n && t.nseg == nseg && t.K == K) { t.tiling = tiling; return OVC_OK; }
-    g_tuned.push_back(TunedShape{M, seg_n, nseg, K, tiling});
+        if (t.M == M && t.seg_n == seg_n && t.nseg == nseg && t.K == K) { t = entry; return OVC_OK; }
+    g_tuned.push_back(entry);
     return OVC_OK;
+}
+
+int ovc_gemm_split_for(int M, int N, int K) {
+    const TunedShape* t = tuned_find(M, N, 1, K);
+    return t && t->split > 1 ? t->split : 1;
 }
 
 // Tuning helper: `iters` back-to-back launches of one GEMM on `stream` (no host work in between).

@@ -10,7 +10,10 @@ namespace {
 // ---------------------------------------------------------------------------------------------
 constexpr int kMaxVec = 8;   // float4 per lane -> d <= 2048
 
-__global__ __launch_bounds__(256) void layer_norm_rows(const float* __restrict__ x, const float* __restrict__ residual,
+// With nparts > 1, x holds nparts partial products of a K-split GEMM (part_stride floats apart): the row is their
+// sum in slice order, plus `bias` -- the epilogue the split GEMM could not apply.
+__global__ __launch_bounds__(256) void layer_norm_rows(const float* __restrict__ x, int nparts, long part_stride,
+                                                       const float* __restrict__ bias, const float* __restrict__ residual,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        const float* __restrict__ add, int add_rows,
                                                        const uint8_t* __restrict__ zero_rows, float eps,
@@ -33,6 +36,8 @@ __global__ __launch_bounds__(256) void layer_norm_rows(const float* __restrict__
         const int c = lane + i * 64;
         if (c < nvec) {
             v[i] = xr[c];
+            for (int s = 1; s < nparts; ++s) v[i] += reinterpret_cast<const f32x4*>(x + s * part_stride + (size_t)row * d)[c];
+            if (bias) v[i] += reinterpret_cast<const f32x4*>(bias)[c];
             if (rr) v[i] += rr[c];
             sum += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
         }
@@ -224,7 +229,19 @@ extern "C" int ovc_layer_norm(const float* x, const float* residual, const float
     if (!ovc_aligned16(x) || !ovc_aligned16(y) || !ovc_aligned16(gamma) || !ovc_aligned16(beta) ||
         (residual && !ovc_aligned16(residual)) || (add && !ovc_aligned16(add))) return OVC_EINVAL;
     hipLaunchKernelGGL(layer_norm_rows, dim3((rows + 3) / 4), dim3(256), 0, ovc_hip_stream(stream),
-                       x, residual, gamma, beta, add, add_rows, zero_rows, eps, y, rows, d);
+                       x, 1, 0L, nullptr, residual, gamma, beta, add, add_rows, zero_rows, eps, y, rows, d);
+    OVC_RETURN_IF_LAUNCH_FAILED();
+    return OVC_OK;
+}
+
+int ovc_layer_norm_parts(const float* parts, int nparts, long part_stride, const float* bias, const float* residual,
+                         const float* gamma, const float* beta, const uint8_t* zero_rows, float eps, float* y,
+                         int rows, int d, hipStream_t stream) {
+    if (!parts || nparts < 1 || !gamma || !beta || !y || rows <= 0 || d <= 0 || (d & 3) || d > 64 * 4 * kMaxVec) return OVC_EINVAL;
+    if ((part_stride & 3) || !ovc_aligned16(parts) || !ovc_aligned16(y) || (bias && !ovc_aligned16(bias)) ||
+        (residual && !ovc_aligned16(residual))) return OVC_EINVAL;
+    hipLaunchKernelGGL(layer_norm_rows, dim3((rows + 3) / 4), dim3(256), 0, stream,
+                       parts, nparts, part_stride, bias, residual, gamma, beta, nullptr, 0, zero_rows, eps, y, rows, d);
     OVC_RETURN_IF_LAUNCH_FAILED();
     return OVC_OK;
 }

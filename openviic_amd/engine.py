@@ -142,7 +142,7 @@ class CaptionEngine:
         if key in self._tuned:
             return
         shapes = self.gemm_shapes(B, N, k)
-        cache_path = os.environ.get("OVC_TUNE_CACHE")       # optional json: {"M,seg_n,nseg,K": tiling}
+        cache_path = os.environ.get("OVC_TUNE_CACHE")       # optional json: {"M,seg_n,nseg,K": ovc_gemm_tuned_get code}
         cache = {}
         if cache_path and os.path.exists(cache_path):
             with open(cache_path) as f:
@@ -151,7 +151,9 @@ class CaptionEngine:
                 name = ",".join(map(str, shape))
                 if name in cache:
                     self.lib.ovc_gemm_tuned_set(*shape, int(cache[name]))
-        need = max(4 * (m * kk + sn * ns * kk + m * sn * ns) + 256 for m, sn, ns, kk in shapes)
+        # operands + output; single-segment shapes also hold the partial outputs of a 4-way K split
+        need = max(4 * (m * kk + sn * ns * kk + m * sn * ns * (4 if ns == 1 and m * sn < 4 << 20 else 1)) + 256
+                   for m, sn, ns, kk in shapes)
         scratch = torch.empty(need // 4 + 16, dtype=torch.float32, device=self.device).normal_()
         for m, sn, ns, kk in shapes:
             check(self.lib.ovc_gemm_tune(m, sn, ns, kk, scratch.data_ptr(), scratch.numel() * 4, native.stream_handle()),

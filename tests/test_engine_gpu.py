@@ -296,3 +296,30 @@ def test_invalid_requests_fail_loudly():
             model.beam_search(batch(feats[:, :, :16].contiguous()), batch_size=feats.shape[0], beam_size=2)
         ids, _ = model.beam_search(batch(feats), batch_size=feats.shape[0], beam_size=3)   # still usable afterwards
     assert ids.shape == (feats.shape[0], TINY_SHAPE["T"])
+
+
+@pytest.mark.parametrize("split", [2, 4])
+def test_k_split_projections_against_reference_golden(split):
+    """The projections back to d_model (self / cross output, second FFN layer) run as K-split GEMMs whose partial
+    products the LayerNorm kernel sums, where the tuner measures that as faster.  Here the choice is preset for
+    the B=16, beam-5 shapes so that the path is exercised whatever the tuner would pick on this device."""
+    from openviic_amd import native
+    lib = native.load()
+    g = golden("g2_full_standard_transformer.npz")
+    B, k = 16, 5
+    cfg, vocab, sd, feats, _ = full_case("standard_transformer", B)
+    for rows in (B, B * k):
+        for K in (512, 2048):
+            code = 3 | split << 8 | 3 << 16                    # plain: 64x64; split: `split` slices of 64x64 tiles
+            assert lib.ovc_gemm_tuned_set(rows, 512, 1, K, code) == 0
+            assert lib.ovc_gemm_tuned_get(rows, 512, 1, K) == code
+    model = device_model(cfg, vocab, sd)
+    with torch.no_grad():
+        ids, logp = model.beam_search(batch(feats), batch_size=B, beam_size=k)
+    p = "B16_k5_"
+    assert_ids_match_where_decided(ids.cpu().numpy(), g[p + "ids"], g[p + "gap"], g[p + "inner_gap"], MARGIN, "k-split")
+    same = (ids.cpu().numpy() == g[p + "ids"]).all(axis=1)
+    assert same.mean() >= 0.9
+    _logp_close(logp.cpu().numpy()[same], g[p + "logp"][same], "k-split logp")
+    assert lib.ovc_gemm_tuned_set(16, 512, 1, 2048, 3 | 8 << 8 | 3 << 16) != 0      # more than 4 slices: refused
+    assert lib.ovc_gemm_tuned_set(16, 512, 3, 2048, 3 | 2 << 8 | 3 << 16) != 0      # segmented outputs cannot split
