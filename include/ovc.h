@@ -111,10 +111,12 @@ int ovc_box_relation_weights(const float* boxes, int b, int n, const float* fc_w
  *   multiplied by "previous word != eos"); selects the k best of the width*V candidates per
  *   image (ties: lower flat index first, as torch's stable sort).  Frozen beams (alive = 0)
  *   offer word 0 at their running score and -999 elsewhere; their rows of logp are rewritten
- *   as logp*0 when masked_logp != NULL.  chosen [B,k] int64 flat indices, score [B,k]. */
+ *   as logp*0 when masked_logp != NULL.  chosen [B,k] int64 flat indices, score [B,k].
+ *   scratch: >= 8*B*width*k bytes of device memory (16-byte aligned) for the per-row candidates the
+ *   two passes exchange (one workgroup per beam row, then a k-way merge per image). */
 int ovc_beam_select(const float* logp, const float* running, const float* alive, int B,
                     int width, int V, int k, int64_t* chosen, float* score, float* masked_logp,
-                    ovc_stream stream);
+                    void* scratch, size_t scratch_bytes, ovc_stream stream);
 
 /* ======================================================================================
  * Engine level: the fused hot path  (models/base_transformer.py:45-53 and everything below it)

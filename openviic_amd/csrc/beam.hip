@@ -9,16 +9,15 @@
 //   * beam = idx / V, word = idx % V; every per-beam quantity follows the selected beam.
 //
 // The reference materialises log_softmax over [B*k, V] and then fully sorts [B, k*V]; here the
-// log-sum-exp, the candidate scores and a k-way partial selection are fused in one pass per image:
-// each thread keeps a sorted list of its k best candidates, then k rounds of a block-wide argmax
-// over the list heads pick the winners.
+// log-sum-exp, the candidate scores and a k-way partial selection are fused in one pass per beam row,
+// and the image's winners are the k best of its rows' k best.
 #include "common.h"
 
 namespace {
 
-constexpr int kSelThreads = 1024;
+constexpr int kSelThreads = 256;
 constexpr int kMaxK = OVC_MAX_BEAM;
-constexpr int kSurvivorCap = 2048;   // LDS list of candidates that can still reach the top k
+constexpr int kSurvivorCap = 1024;   // LDS list of candidates that can still reach the row's top k
 
 struct Cand { float v; int idx; };
 
@@ -64,121 +63,110 @@ __device__ __forceinline__ Cand wave_topk(const float (&lv)[kMaxK], const int (&
     return mine;
 }
 
-// One workgroup (1024 threads = 16 waves) per image.  The image's width*V logits are read from
-// memory exactly once into registers (all loads in flight together: the kernel is latency-bound, not
-// bandwidth-bound); the log-sum-exp of every live row and the candidate scores are computed from those
-// registers.  Selection is threshold based: the k-th best of a wave's lane maxima bounds the k-th best
-// overall from below, so only the handful of candidates at or above that bound are collected (LDS list)
-// and ranked by one wave -- no per-candidate sorted-list maintenance on the hot path.
-template <int kPerThread, int kRows, int kVec>
-__global__ __launch_bounds__(kSelThreads) void beam_select_kernel(BeamSelectArgs p) {
-    constexpr int kElems = kPerThread * kVec;      // logits per thread per row; element (j, e) is column kVec*(tid + j*1024) + e
-    __shared__ float red_max[16][kMaxK], red_sum[16][kMaxK];
-    __shared__ float thr[16];
+// One workgroup (256 threads) per beam row -- B*width workgroups, several resident per CU, so one row's
+// loads overlap another row's reductions (a single 1024-thread workgroup per image ran the same phases in
+// lock-step on every CU: 30 us for 52 MB at B=256; per-row workgroups stream it at HBM rate).  The row's V
+// logits are read once into registers (all loads in flight together); log-sum-exp, candidate scores and the
+// row's k best candidates come from those registers.  Selection is threshold based: the k-th best of a wave's
+// lane maxima bounds the row's k-th best from below, so only the few candidates at or above the largest such
+// bound are collected (LDS list) and ranked by one wave.  The image's k winners are the k best of its rows'
+// candidates (merged by beam_update_kernel / beam_merge_kernel with the same order: score, then flat index).
+template <int kPerThread, int kVec>
+__global__ __launch_bounds__(kSelThreads) void beam_row_select_kernel(BeamSelectArgs p) {
+    constexpr int kElems = kPerThread * kVec;      // logits per thread; element (j, e) is column kVec*(tid + j*256) + e
+    constexpr int kWaves = kSelThreads / 64;
+    __shared__ float red[kWaves];
+    __shared__ float thr[kWaves];
     __shared__ int count;
     __shared__ float surv_v[kSurvivorCap];
     __shared__ int surv_i[kSurvivorCap];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int b = blockIdx.x;
+    const int row = blockIdx.x;
     const int W = p.width, V = p.V, k = p.k;
-    const float* x = p.logits + (size_t)b * W * p.ld;
+    const int i = row % W;                          // beam of this row inside its image
+    const float run = p.running[row];
+    const float alive = p.alive ? p.alive[row] : 1.0f;
+    const bool live = alive != 0.0f;                // uniform over the workgroup
+    float* cand_v = p.cand_v + (size_t)row * k;
+    int* cand_i = p.cand_i + (size_t)row * k;
 
-    float xv[kRows][kElems];
+    if (!live && !p.masked_logp) {
+        // A frozen beam (it has emitted <eos>) offers word 0 at its running score and -999 for every other word
+        // (beam_search.py:52-55): its k best are words 0..k-1, whatever the logits are.
+        if (tid < k) {
+            cand_v[tid] = tid == 0 ? run : (tid < V ? -999.0f : -INFINITY);
+            cand_i[tid] = tid < V ? i * V + tid : 0x7fffffff;
+        }
+        if (tid == 0 && p.row_max_out) { p.row_max_out[row] = 0.f; p.row_lsum_out[row] = 0.f; }   // lp is multiplied by alive = 0
+        return;
+    }
+
+    const float* x = p.logits + (size_t)row * p.ld;
+    float xv[kElems];
 #pragma unroll
-    for (int i = 0; i < kRows; ++i) {
-        if (i < W) {
+    for (int j = 0; j < kPerThread; ++j) {
+        const int c0 = kVec * (tid + j * kSelThreads);
+        // unconditional loads from clamped (always valid) addresses; the tail is masked afterwards, so that all of
+        // a thread's loads are in flight together (a guarded load costs a vmcnt(0) each)
+        if (kVec == 4) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(x + min(c0, (V - 1) & ~3));   // rows are 16-byte aligned
 #pragma unroll
-            for (int j = 0; j < kPerThread; ++j) {
-                const int c0 = kVec * (tid + j * kSelThreads);
-                // unconditional loads from clamped (always valid) addresses; the tail is masked afterwards, so
-                // that all of a thread's loads are in flight together (a guarded load costs a vmcnt(0) each)
-                if (kVec == 4) {
-                    // rows are 16-byte aligned (ld % 4 == 0): one 16-byte load per lane
-                    const f32x4 v = *reinterpret_cast<const f32x4*>(x + (size_t)i * p.ld + min(c0, (V - 1) & ~3));
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) xv[i][j * 4 + e] = c0 + e < V ? v[e] : -INFINITY;
-                } else {
-                    const float v = x[(size_t)i * p.ld + min(c0, V - 1)];
-                    xv[i][j] = c0 < V ? v : -INFINITY;
-                }
-            }
+            for (int e = 0; e < 4; ++e) xv[j * 4 + e] = c0 + e < V ? v[e] : -INFINITY;
+        } else {
+            const float v = x[min(c0, V - 1)];
+            xv[j] = c0 < V ? v : -INFINITY;
         }
     }
 
-    // ---- log-sum-exp per row: (x - max) - log(sum exp(x - max)), as ATen's log_softmax -----------------
-    float mx[kRows], ls[kRows];
+    // ---- log-sum-exp: (x - max) - log(sum exp(x - max)), as ATen's log_softmax ------------------------------
+    float mx = 0.f, ls = 0.f;
     if (!p.is_logp) {
+        float m = -INFINITY;
 #pragma unroll
-        for (int i = 0; i < kRows; ++i) {
-            if (i < W) {
-                float m = -INFINITY;
-#pragma unroll
-                for (int j = 0; j < kElems; ++j) m = fmaxf(m, xv[i][j]);
-                m = wave_max(m);
-                if (lane == 0) red_max[wave][i] = m;
-            }
-        }
+        for (int j = 0; j < kElems; ++j) m = fmaxf(m, xv[j]);
+        m = wave_max(m);
+        if (lane == 0) red[wave] = m;
         __syncthreads();
+        m = red[0];
 #pragma unroll
-        for (int i = 0; i < kRows; ++i) {
-            if (i < W) {
-                float m = red_max[0][i];
+        for (int w = 1; w < kWaves; ++w) m = fmaxf(m, red[w]);
+        mx = m;
+        float sum = 0.f;
 #pragma unroll
-                for (int w = 1; w < 16; ++w) m = fmaxf(m, red_max[w][i]);
-                mx[i] = m;
-                float sum = 0.f;
-#pragma unroll
-                for (int j = 0; j < kElems; ++j) sum += __expf(xv[i][j] - m);   // v_exp_f32 path (|rel err| ~2e-7 per term); exp(-inf) = 0 for the tail
-                sum = wave_sum(sum);
-                if (lane == 0) red_sum[wave][i] = sum;
-            }
-        }
+        for (int j = 0; j < kElems; ++j) sum += __expf(xv[j] - m);   // v_exp_f32 path (|rel err| ~2e-7 per term); exp(-inf) = 0 for the tail
+        sum = wave_sum(sum);
         __syncthreads();
+        if (lane == 0) red[wave] = sum;
+        __syncthreads();
+        float tot = 0.f;
 #pragma unroll
-        for (int i = 0; i < kRows; ++i) {
-            if (i < W) {
-                float tot = 0.f;
-#pragma unroll
-                for (int w = 0; w < 16; ++w) tot += red_sum[w][i];
-                ls[i] = logf(tot);
-            }
-        }
-    } else {
-#pragma unroll
-        for (int i = 0; i < kRows; ++i) { mx[i] = 0.f; ls[i] = 0.f; }
+        for (int w = 0; w < kWaves; ++w) tot += red[w];
+        ls = logf(tot);
     }
+    if (tid == 0 && p.row_max_out) { p.row_max_out[row] = mx; p.row_lsum_out[row] = ls; }
 
-    // ---- candidate scores (kept in the logit registers) and each lane's best -------------------------------
+    // ---- candidate scores (kept in the logit registers) and each lane's best ------------------------------------
+    // seq_mask * candidate + frozen * (1 - seq_mask) (beam_search.py:52-55) with seq_mask in {0, 1}: a live beam's
+    // score is exactly run + lp (x + 0 == x), a frozen beam's exactly `frozen`.  A thread visits flat indices in
+    // increasing order, hence a strict > keeps the lower index on ties.
     float bv = -INFINITY;
     int bi = 0x7fffffff;
+    float* mrow = p.masked_logp ? p.masked_logp + (size_t)row * V : nullptr;
 #pragma unroll
-    for (int i = 0; i < kRows; ++i) {
-        if (i < W) {
-            const float run = p.running[b * W + i];
-            const float alive = p.alive ? p.alive[b * W + i] : 1.0f;
-            float* mrow = p.masked_logp ? p.masked_logp + ((size_t)b * W + i) * V : nullptr;
-            // seq_mask * candidate + frozen * (1 - seq_mask) (beam_search.py:52-55) with seq_mask in {0, 1}: a live
-            // beam's score is exactly run + lp (x + 0 == x), a frozen beam's exactly `frozen`; `alive` is uniform
-            // over the workgroup, so the branch is free.  A thread visits flat indices in increasing order, hence
-            // a strict > keeps the lower index on ties.
-            const bool live = alive != 0.0f;
-#pragma unroll
-            for (int j = 0; j < kElems; ++j) {
-                const int c = kVec * (tid + (j / kVec) * kSelThreads) + (j % kVec);
-                float cand = -INFINITY;
-                if (c < V) {
-                    const float lp = (xv[i][j] - mx[i]) - ls[i];
-                    if (mrow) mrow[c] = lp * alive;
-                    cand = live ? run + lp : (c == 0 ? run : -999.0f);
-                    if (cand > bv) { bv = cand; bi = i * V + c; }
-                }
-                xv[i][j] = cand;
-            }
+    for (int j = 0; j < kElems; ++j) {
+        const int c = kVec * (tid + (j / kVec) * kSelThreads) + (j % kVec);
+        float cand = -INFINITY;
+        if (c < V) {
+            const float lp = (xv[j] - mx) - ls;
+            if (mrow) mrow[c] = lp * alive;
+            cand = live ? run + lp : (c == 0 ? run : -999.0f);
+            if (cand > bv) { bv = cand; bi = i * V + c; }
         }
+        xv[j] = cand;
     }
 
-    // ---- a lower bound T on the k-th best: the k-th best of one wave's lane maxima (k distinct
-    //      candidates are >= it), tightened by taking the largest such bound over the 16 waves -----------------
+    // ---- a lower bound on the row's k-th best: the k-th best of one wave's lane maxima (k distinct candidates
+    //      are >= it), tightened by taking the largest such bound over the waves ---------------------------------------
     {
         float cv = bv;
         int ci = bi;
@@ -195,79 +183,66 @@ __global__ __launch_bounds__(kSelThreads) void beam_select_kernel(BeamSelectArgs
     __syncthreads();
     float T = thr[0];
 #pragma unroll
-    for (int w = 1; w < 16; ++w) T = fmaxf(T, thr[w]);
+    for (int w = 1; w < kWaves; ++w) T = fmaxf(T, thr[w]);
 
-    // ---- survivors (score >= T; usually a few dozen) are appended to an LDS list --------------------------------
+    // ---- survivors (score >= T; usually a few dozen) are appended to an LDS list -------------------------------------
 #pragma unroll
-    for (int i = 0; i < kRows; ++i) {
-        if (i < W) {
-#pragma unroll
-            for (int j = 0; j < kElems; ++j) {
-                const int c = kVec * (tid + (j / kVec) * kSelThreads) + (j % kVec);
-                if (c < V && xv[i][j] >= T) {
-                    const int pos = atomicAdd(&count, 1);
-                    if (pos < kSurvivorCap) { surv_v[pos] = xv[i][j]; surv_i[pos] = i * V + c; }
-                }
-            }
+    for (int j = 0; j < kElems; ++j) {
+        const int c = kVec * (tid + (j / kVec) * kSelThreads) + (j % kVec);
+        if (c < V && xv[j] >= T) {
+            const int pos = atomicAdd(&count, 1);
+            if (pos < kSurvivorCap) { surv_v[pos] = xv[j]; surv_i[pos] = i * V + c; }
         }
     }
     __syncthreads();
     const int nsurv = count;
+    float mv[kMaxK];
+    int mi[kMaxK];
+#pragma unroll
+    for (int s = 0; s < kMaxK; ++s) { mv[s] = -INFINITY; mi[s] = 0x7fffffff; }
     if (nsurv <= kSurvivorCap) {
-        if (wave == 0) {
-            float mv[kMaxK];
-            int mi[kMaxK];
-#pragma unroll
-            for (int s = 0; s < kMaxK; ++s) { mv[s] = -INFINITY; mi[s] = 0x7fffffff; }
-            for (int e = lane; e < nsurv; e += 64) list_insert(mv, mi, k, surv_v[e], surv_i[e]);
-            const Cand best = wave_topk(mv, mi, k, lane);
-            if (lane < k) {
-                p.chosen[b * k + lane] = (int64_t)best.idx;
-                p.score[b * k + lane] = best.v;
-            }
-        }
+        if (wave != 0) return;
+        for (int e = lane; e < nsurv; e += 64) list_insert(mv, mi, k, surv_v[e], surv_i[e]);
     } else {
-        // Massive ties (e.g. a live beam fed <pad> yields a uniform row: V equal scores).  Exhaustive path:
-        // per-lane sorted lists over all candidates, wave top-k, merge by wave 0.
-        float lv[kMaxK];
-        int li[kMaxK];
+        // Massive ties (a live beam fed <pad> yields a uniform row: V equal scores; a frozen row when all
+        // log-probs are wanted).  Exhaustive path: per-lane sorted lists over all candidates, wave top-k, merged
+        // by wave 0.
 #pragma unroll
-        for (int s = 0; s < kMaxK; ++s) { lv[s] = -INFINITY; li[s] = 0x7fffffff; }
-#pragma unroll
-        for (int i = 0; i < kRows; ++i) {
-            if (i < W) {
-#pragma unroll
-                for (int j = 0; j < kElems; ++j) {
-                    const int c = kVec * (tid + (j / kVec) * kSelThreads) + (j % kVec);
-                    if (c < V && better(xv[i][j], i * V + c, lv[k - 1], li[k - 1])) list_insert(lv, li, k, xv[i][j], i * V + c);
-                }
-            }
+        for (int j = 0; j < kElems; ++j) {
+            const int c = kVec * (tid + (j / kVec) * kSelThreads) + (j % kVec);
+            if (c < V && better(xv[j], i * V + c, mv[k - 1], mi[k - 1])) list_insert(mv, mi, k, xv[j], i * V + c);
         }
-        const Cand wbest = wave_topk(lv, li, k, lane);
+        const Cand wbest = wave_topk(mv, mi, k, lane);
         __syncthreads();                       // the survivor list is dead: reuse its head as the merge buffer
         if (lane < k) { surv_v[wave * k + lane] = wbest.v; surv_i[wave * k + lane] = wbest.idx; }
         __syncthreads();
-        if (wave == 0) {
-            float mv[kMaxK];
-            int mi[kMaxK];
+        if (wave != 0) return;
 #pragma unroll
-            for (int s = 0; s < kMaxK; ++s) { mv[s] = -INFINITY; mi[s] = 0x7fffffff; }
-            for (int e = lane; e < 16 * k; e += 64) list_insert(mv, mi, k, surv_v[e], surv_i[e]);
-            const Cand best = wave_topk(mv, mi, k, lane);
-            if (lane < k) {
-                p.chosen[b * k + lane] = (int64_t)best.idx;
-                p.score[b * k + lane] = best.v;
-            }
-        }
+        for (int s = 0; s < kMaxK; ++s) { mv[s] = -INFINITY; mi[s] = 0x7fffffff; }
+        for (int e = lane; e < kWaves * k; e += 64) list_insert(mv, mi, k, surv_v[e], surv_i[e]);
     }
-    if (p.row_max_out && wave == 1 && lane < W) {
-        // mx / ls are identical in every thread; pick them with a static-index select
-        float m = 0.f, l = 0.f;
-#pragma unroll
-        for (int i = 0; i < kRows; ++i)
-            if (i == lane) { m = mx[i]; l = ls[i]; }
-        p.row_max_out[b * W + lane] = m;
-        p.row_lsum_out[b * W + lane] = l;
+    const Cand best = wave_topk(mv, mi, k, lane);
+    if (lane < k) { cand_v[lane] = best.v; cand_i[lane] = best.idx; }
+}
+
+// The k best of an image's width*k row candidates, in order; lane r < k of the (single) wave returns the r-th.
+__device__ __forceinline__ Cand merge_row_candidates(const float* cand_v, const int* cand_i, int b, int W, int k, int lane) {
+    Cand c; c.v = -INFINITY; c.idx = 0x7fffffff;
+    if (lane < W * k) { c.v = cand_v[(size_t)b * W * k + lane]; c.idx = cand_i[(size_t)b * W * k + lane]; }
+    Cand mine = c;
+    for (int round = 0; round < k; ++round) {
+        const Cand w = wave_best(c);
+        if (lane == round) mine = w;
+        if (c.idx == w.idx) { c.v = -INFINITY; c.idx = 0x7fffffff; }      // flat indices are unique
+    }
+    return mine;
+}
+
+__global__ __launch_bounds__(64) void beam_merge_kernel(BeamSelectArgs p) {
+    const Cand best = merge_row_candidates(p.cand_v, p.cand_i, blockIdx.x, p.width, p.k, threadIdx.x);
+    if ((int)threadIdx.x < p.k) {
+        p.chosen[blockIdx.x * p.k + threadIdx.x] = (int64_t)best.idx;
+        p.score[blockIdx.x * p.k + threadIdx.x] = best.v;
     }
 }
 
@@ -278,14 +253,15 @@ __global__ __launch_bounds__(64) void beam_update_kernel(BeamUpdateArgs p) {
     const int b = blockIdx.x, tid = threadIdx.x;
     const int k = p.k, W = p.width, V = p.V, T = p.T, t = p.t;
     __shared__ int parent[kMaxK], word[kMaxK];
+    const Cand best = merge_row_candidates(p.cand_v, p.cand_i, b, W, k, tid);
     if (tid < k) {
-        const int f = (int)p.chosen[b * k + tid];
+        const int f = best.idx;
         const int par = f / V, wd = f - par * V;
         parent[tid] = par; word[tid] = wd;
         const float alive = p.alive_in[b * W + par];
         const float x = p.logits[((size_t)b * W + par) * p.ld + wd];
         const float lp = ((x - p.row_max[b * W + par]) - p.row_lsum[b * W + par]) * alive;
-        p.running_out[b * k + tid] = p.score[b * k + tid];
+        p.running_out[b * k + tid] = best.v;
         p.alive_out[b * k + tid] = alive * (wd != p.eos ? 1.0f : 0.0f);
         p.hist_out[((size_t)b * k + tid) * T + t] = wd;
         p.lp_out[((size_t)b * k + tid) * T + t] = lp;
@@ -340,35 +316,31 @@ __global__ __launch_bounds__(256) void beam_gather_all_kernel(const float* __res
 
 }  // namespace
 
+// Row pass: p.cand_v / p.cand_i [B*width][k] receive every row's k best candidates (flat index beam*V + word).
+// With p.chosen set, a second tiny kernel merges them into the image's k winners (the engine's update kernel
+// does that merge itself).
 int ovc_beam_select_launch(const BeamSelectArgs& p, int B, hipStream_t stream) {
-    if (B <= 0 || p.width <= 0 || p.width > kMaxK || p.k <= 0 || p.k > kMaxK || p.V <= 0) return OVC_EINVAL;
+    if (B <= 0 || p.width <= 0 || p.width > kMaxK || p.k <= 0 || p.k > kMaxK || p.V <= 0 || !p.cand_v || !p.cand_i) return OVC_EINVAL;
     if ((long)p.width * p.V < p.k || (long)p.width * p.V > 0x7fffffffL) return OVC_EINVAL;
-    const dim3 grid(B), block(kSelThreads);
+    const dim3 grid(B * p.width), block(kSelThreads);
     const bool vec = (p.ld & 3) == 0 && ovc_aligned16(p.logits);
-#define OVC_SELECT(PT, ROWS, VEC) hipLaunchKernelGGL((beam_select_kernel<PT, ROWS, VEC>), grid, block, 0, stream, p)
+#define OVC_SELECT(PT, VEC) hipLaunchKernelGGL((beam_row_select_kernel<PT, VEC>), grid, block, 0, stream, p)
     if (vec) {
         const int per_thread = (p.V + 4 * kSelThreads - 1) / (4 * kSelThreads);      // 16-byte loads
-        if (p.width == 1) {
-            if (per_thread <= 1) OVC_SELECT(1, 1, 4); else if (per_thread <= 4) OVC_SELECT(4, 1, 4); else return OVC_EINVAL;
-        } else if (p.width <= 5) {
-            if (per_thread <= 1) OVC_SELECT(1, 5, 4); else if (per_thread <= 3) OVC_SELECT(3, 5, 4); else return OVC_EINVAL;
-        } else {
-            if (per_thread <= 1) OVC_SELECT(1, 8, 4); else if (per_thread <= 3) OVC_SELECT(3, 8, 4); else return OVC_EINVAL;
-        }
+        if (per_thread <= 1) OVC_SELECT(1, 4); else if (per_thread <= 4) OVC_SELECT(4, 4);
+        else if (per_thread <= 10) OVC_SELECT(10, 4); else if (per_thread <= 16) OVC_SELECT(16, 4); else return OVC_EINVAL;
     } else {
         const int per_thread = (p.V + kSelThreads - 1) / kSelThreads;
-        if (p.width == 1) {
-            if (per_thread <= 4) OVC_SELECT(4, 1, 1); else if (per_thread <= 16) OVC_SELECT(16, 1, 1); else return OVC_EINVAL;
-        } else if (p.width <= 5) {
-            if (per_thread <= 4) OVC_SELECT(4, 5, 1); else if (per_thread <= 10) OVC_SELECT(10, 5, 1);
-            else if (per_thread <= 16) OVC_SELECT(16, 5, 1); else return OVC_EINVAL;
-        } else {
-            if (per_thread <= 4) OVC_SELECT(4, 8, 1); else if (per_thread <= 10) OVC_SELECT(10, 8, 1); else return OVC_EINVAL;
-        }
+        if (per_thread <= 4) OVC_SELECT(4, 1); else if (per_thread <= 16) OVC_SELECT(16, 1);
+        else if (per_thread <= 40) OVC_SELECT(40, 1); else if (per_thread <= 64) OVC_SELECT(64, 1); else return OVC_EINVAL;
     }
 #undef OVC_SELECT
-    // (vocabularies above 12288-16384 words, or above 10240-12288 with beams wider than 5, are not supported yet)
+    // (vocabularies above 16384 words are not supported yet)
     OVC_RETURN_IF_LAUNCH_FAILED();
+    if (p.chosen) {
+        hipLaunchKernelGGL(beam_merge_kernel, dim3(B), dim3(64), 0, stream, p);
+        OVC_RETURN_IF_LAUNCH_FAILED();
+    }
     return OVC_OK;
 }
 
@@ -392,9 +364,14 @@ int ovc_beam_gather_all_launch(const float* all_buf, const int* order, int B, in
 }
 
 extern "C" int ovc_beam_select(const float* logp, const float* running, const float* alive, int B, int width, int V,
-                               int k, int64_t* chosen, float* score, float* masked_logp, ovc_stream stream) {
-    if (!logp || !running || !chosen || !score) return OVC_EINVAL;
+                               int k, int64_t* chosen, float* score, float* masked_logp, void* scratch,
+                               size_t scratch_bytes, ovc_stream stream) {
+    if (!logp || !running || !chosen || !score || B <= 0 || width <= 0 || k <= 0) return OVC_EINVAL;
+    const size_t rows_k = (size_t)B * width * k;
+    if (!scratch || !ovc_aligned16(scratch) || scratch_bytes < 8 * rows_k) return OVC_EWORKSPACE;
     BeamSelectArgs p{};
+    p.cand_v = reinterpret_cast<float*>(scratch);
+    p.cand_i = reinterpret_cast<int*>(scratch) + rows_k;
     p.logits = logp; p.ld = V; p.is_logp = 1;
     p.running = running; p.alive = alive;
     p.width = width; p.V = V; p.k = k;

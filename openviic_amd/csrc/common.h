@@ -64,7 +64,8 @@ int ovc_gemm_pick_tiling(const GemmArgs& args);      // index of the tiling ovc_
 // outputs (1 = none; also for shapes that were never tuned).  At most kMaxKSplit.
 constexpr int kMaxKSplit = 4;
 int ovc_gemm_split_for(int M, int N, int K);
-// LayerNorm(sum_s parts[s] + bias + residual): the consumer side of a K-split GEMM (rowops.hip).
+// LayerNorm(sum_s parts[s] + bias + residual), nparts in {2, 4}, bias and residual required: the consumer side of
+// a K-split GEMM (rowops.hip).
 int ovc_layer_norm_parts(const float* parts, int nparts, long part_stride, const float* bias, const float* residual,
                          const float* gamma, const float* beta, const uint8_t* zero_rows, float eps, float* y,
                          int rows, int d, hipStream_t stream);
@@ -113,7 +114,9 @@ struct BeamSelectArgs {
     const float* running;    // [B, width]
     const float* alive;      // [B, width] or nullptr (all alive)
     int width, V, k;
-    int64_t* chosen;         // [B, k] flat indices beam*V + word
+    float* cand_v;           // [B*width, k] every row's k best candidate scores ...
+    int* cand_i;             // ... and their flat indices beam*V + word (0x7fffffff = none)
+    int64_t* chosen;         // [B, k] the image's winners (flat indices), or nullptr when the caller merges the rows
     float* score;            // [B, k]
     float* masked_logp;      // [B, width, V] or nullptr
     float* row_max_out;      // [B, width] or nullptr: log-softmax pieces for the update kernel
@@ -122,7 +125,7 @@ struct BeamSelectArgs {
 int ovc_beam_select_launch(const BeamSelectArgs& p, int B, hipStream_t stream);
 
 struct BeamUpdateArgs {
-    const int64_t* chosen; const float* score;
+    const float* cand_v; const int* cand_i;         // [B*width, k] row candidates of ovc_beam_select_launch
     const float* logits; int ld;
     const float* row_max; const float* row_lsum;
     const float* alive_in; float* alive_out; float* running_out;

@@ -96,7 +96,7 @@ struct Workspace {
     uint8_t* padflag;                             // [T][R]
     float* logits;                                // [R][V]
     float* running[2]; float* alive[2]; int32_t* hist[2]; float* lp[2]; int32_t* anc[2];
-    int32_t* tok; int64_t* chosen; float* score; float* row_max; float* row_lsum; int32_t* order;
+    int32_t* tok; float* cand_v; int32_t* cand_i; float* row_max; float* row_lsum; int32_t* order;
     float* all_buf;
     int64_t* out_ids; float* out_logp;            // graph replay writes here, then copied to the caller
     size_t bytes;
@@ -151,7 +151,7 @@ Workspace carve(const ovc_model* m, void* base, int B, int N, int k, int return_
         w.running[i] = a.take<float>(R); w.alive[i] = a.take<float>(R);
         w.hist[i] = a.take<int32_t>(R * T); w.lp[i] = a.take<float>(R * T); w.anc[i] = a.take<int32_t>(R * T);
     }
-    w.tok = a.take<int32_t>(R); w.chosen = a.take<int64_t>(R); w.score = a.take<float>(R);
+    w.tok = a.take<int32_t>(R); w.cand_v = a.take<float>(R * (size_t)k); w.cand_i = a.take<int32_t>(R * (size_t)k);
     w.row_max = a.take<float>(R); w.row_lsum = a.take<float>(R); w.order = a.take<int32_t>(R);
     w.all_buf = a.take<float>(return_probs ? T * R * (size_t)m->vocab : 0);
     w.out_ids = a.take<int64_t>(R * T); w.out_logp = a.take<float>(R * T);
@@ -239,8 +239,8 @@ struct Engine {
     int linear_ln(const float* x, int K, const ovc_lin& l, const float* residual, const ovc_norm& ln,
                   const uint8_t* zero_rows, float* y_tmp, float* part, float* out, int M) {
         const int d = m->d_model;
-        const int split = part ? ovc_gemm_split_for(M, d, K) : 1;
-        if (split <= 1) {
+        const int split = part && l.b && residual ? ovc_gemm_split_for(M, d, K) : 1;
+        if (split != 2 && split != 4) {
             TRY(linear(x, K, l, residual, y_tmp, M, d, 0));
             return ovc_layer_norm(y_tmp, nullptr, ln.g, ln.b, nullptr, 0, zero_rows, m->ln_eps, out, M, d, stream);
         }
@@ -449,12 +449,12 @@ int run_decode_step(Engine& e, Workspace& w, int B, int N, int k, int t, int ret
     BeamSelectArgs bs{};
     bs.logits = w.logits; bs.ld = ldv; bs.is_logp = 0;
     bs.running = w.running[cur]; bs.alive = w.alive[cur]; bs.width = width; bs.V = m->vocab; bs.k = k;
-    bs.chosen = w.chosen; bs.score = w.score;
+    bs.cand_v = w.cand_v; bs.cand_i = w.cand_i; bs.chosen = nullptr; bs.score = nullptr;   // merged by the update kernel
     bs.masked_logp = return_probs ? w.all_buf + (size_t)t * R * m->vocab : nullptr;
     bs.row_max_out = w.row_max; bs.row_lsum_out = w.row_lsum;
     TRY(ovc_beam_select_launch(bs, B, s));
     BeamUpdateArgs bu{};
-    bu.chosen = w.chosen; bu.score = w.score; bu.logits = w.logits; bu.ld = ldv;
+    bu.cand_v = w.cand_v; bu.cand_i = w.cand_i; bu.logits = w.logits; bu.ld = ldv;
     bu.row_max = w.row_max; bu.row_lsum = w.row_lsum;
     bu.alive_in = w.alive[cur]; bu.alive_out = w.alive[nxt]; bu.running_out = w.running[nxt];
     bu.hist_in = w.hist[cur]; bu.hist_out = w.hist[nxt]; bu.lp_in = w.lp[cur]; bu.lp_out = w.lp[nxt];

@@ -6,13 +6,20 @@ namespace {
 
 // ---------------------------------------------------------------------------------------------
 // LayerNorm(x + residual) * gamma + beta + add, optional row zeroing.  One wave per row, the row
-// lives in registers (d <= 64 * 4 * kMaxVec), two-pass mean / variance like ATen's CPU kernel.
+// lives in registers (kVecs float4 per lane, d <= 64 * 4 * kMaxVec), two-pass mean / variance like
+// ATen's CPU kernel.
+//
+// With kParts > 1, x holds kParts partial products of a K-split GEMM (part_stride floats apart): the row is
+// their sum in slice order, plus `bias` -- the epilogue the split GEMM could not apply.
+//
+// Everything a row needs (slices, bias, residual) is loaded before the first use: the operand set is a
+// template parameter, because hipcc turns every run-time "load or skip" into a branch with a full
+// s_waitcnt, which serialised the 3..6 loads of a row into as many memory round trips.
 // ---------------------------------------------------------------------------------------------
 constexpr int kMaxVec = 8;   // float4 per lane -> d <= 2048
 
-// With nparts > 1, x holds nparts partial products of a K-split GEMM (part_stride floats apart): the row is their
-// sum in slice order, plus `bias` -- the epilogue the split GEMM could not apply.
-__global__ __launch_bounds__(256) void layer_norm_rows(const float* __restrict__ x, int nparts, long part_stride,
+template <int kVecs, int kParts, bool kBias, bool kRes>
+__global__ __launch_bounds__(256) void layer_norm_rows(const float* __restrict__ x, long part_stride,
                                                        const float* __restrict__ bias, const float* __restrict__ residual,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        const float* __restrict__ add, int add_rows,
@@ -23,31 +30,45 @@ __global__ __launch_bounds__(256) void layer_norm_rows(const float* __restrict__
     if (row >= rows) return;
     const int nvec = d >> 2;
     float* yrow = y + (size_t)row * d;
-    if (zero_rows && zero_rows[row]) {
+    const bool cleared = zero_rows && zero_rows[row];      // consumed after the row's loads are in flight
+    // column group of (lane, i), clamped in-range: out-of-range lanes load a valid address and are masked later
+    int col[kVecs];
+#pragma unroll
+    for (int i = 0; i < kVecs; ++i) col[i] = min(lane + i * 64, nvec - 1);
+    f32x4 part[kParts][kVecs], bv[kVecs], rv[kVecs];
+#pragma unroll
+    for (int s = 0; s < kParts; ++s)
+#pragma unroll
+        for (int i = 0; i < kVecs; ++i)
+            part[s][i] = reinterpret_cast<const f32x4*>(x + s * part_stride + (size_t)row * d)[col[i]];
+    if (kBias) {
+#pragma unroll
+        for (int i = 0; i < kVecs; ++i) bv[i] = reinterpret_cast<const f32x4*>(bias)[col[i]];
+    }
+    if (kRes) {
+#pragma unroll
+        for (int i = 0; i < kVecs; ++i) rv[i] = reinterpret_cast<const f32x4*>(residual + (size_t)row * d)[col[i]];
+    }
+    if (cleared) {
         for (int c = lane; c < nvec; c += 64) reinterpret_cast<f32x4*>(yrow)[c] = f32x4{0.f, 0.f, 0.f, 0.f};
         return;
     }
-    const f32x4* xr = reinterpret_cast<const f32x4*>(x + (size_t)row * d);
-    const f32x4* rr = residual ? reinterpret_cast<const f32x4*>(residual + (size_t)row * d) : nullptr;
-    f32x4 v[kMaxVec];
+    f32x4 v[kVecs];
     float sum = 0.f;
 #pragma unroll
-    for (int i = 0; i < kMaxVec; ++i) {
-        const int c = lane + i * 64;
-        if (c < nvec) {
-            v[i] = xr[c];
-            for (int s = 1; s < nparts; ++s) v[i] += reinterpret_cast<const f32x4*>(x + s * part_stride + (size_t)row * d)[c];
-            if (bias) v[i] += reinterpret_cast<const f32x4*>(bias)[c];
-            if (rr) v[i] += rr[c];
-            sum += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
-        }
+    for (int i = 0; i < kVecs; ++i) {
+        v[i] = part[0][i];
+#pragma unroll
+        for (int s = 1; s < kParts; ++s) v[i] += part[s][i];
+        if (kBias) v[i] += bv[i];
+        if (kRes) v[i] += rv[i];
+        if (lane + i * 64 < nvec) sum += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
     }
     const float mean = wave_sum(sum) / (float)d;
     float sq = 0.f;
 #pragma unroll
-    for (int i = 0; i < kMaxVec; ++i) {
-        const int c = lane + i * 64;
-        if (c < nvec) {
+    for (int i = 0; i < kVecs; ++i) {
+        if (lane + i * 64 < nvec) {
             const f32x4 t = v[i] - mean;
             sq += (t[0] * t[0] + t[1] * t[1]) + (t[2] * t[2] + t[3] * t[3]);
         }
@@ -55,7 +76,7 @@ __global__ __launch_bounds__(256) void layer_norm_rows(const float* __restrict__
     const float rstd = 1.0f / sqrtf(wave_sum(sq) / (float)d + eps);
     const f32x4* ar = add ? reinterpret_cast<const f32x4*>(add + (size_t)(row % add_rows) * d) : nullptr;
 #pragma unroll
-    for (int i = 0; i < kMaxVec; ++i) {
+    for (int i = 0; i < kVecs; ++i) {
         const int c = lane + i * 64;
         if (c < nvec) {
             f32x4 o = (v[i] - mean) * rstd * reinterpret_cast<const f32x4*>(gamma)[c] + reinterpret_cast<const f32x4*>(beta)[c];
@@ -63,6 +84,20 @@ __global__ __launch_bounds__(256) void layer_norm_rows(const float* __restrict__
             reinterpret_cast<f32x4*>(yrow)[c] = o;
         }
     }
+}
+
+template <int kParts, bool kBias, bool kRes>
+int launch_layer_norm(const float* x, long part_stride, const float* bias, const float* residual, const float* gamma,
+                      const float* beta, const float* add, int add_rows, const uint8_t* zero_rows, float eps, float* y,
+                      int rows, int d, hipStream_t stream) {
+    const int vecs = ((d >> 2) + 63) / 64;
+    const dim3 grid((rows + 3) / 4), block(256);
+#define OVC_LN(V) hipLaunchKernelGGL((layer_norm_rows<V, kParts, kBias, kRes>), grid, block, 0, stream, x, part_stride, bias, \
+                                     residual, gamma, beta, add, add_rows, zero_rows, eps, y, rows, d)
+    if (vecs <= 1) OVC_LN(1); else if (vecs <= 2) OVC_LN(2); else if (vecs <= 4) OVC_LN(4); else OVC_LN(8);
+#undef OVC_LN
+    OVC_RETURN_IF_LAUNCH_FAILED();
+    return OVC_OK;
 }
 
 // mask[r] = (sum_f x[r,f] == 0): one wave per row, 16-byte coalesced loads.
@@ -228,22 +263,19 @@ extern "C" int ovc_layer_norm(const float* x, const float* residual, const float
     if (add && add_rows <= 0) return OVC_EINVAL;
     if (!ovc_aligned16(x) || !ovc_aligned16(y) || !ovc_aligned16(gamma) || !ovc_aligned16(beta) ||
         (residual && !ovc_aligned16(residual)) || (add && !ovc_aligned16(add))) return OVC_EINVAL;
-    hipLaunchKernelGGL(layer_norm_rows, dim3((rows + 3) / 4), dim3(256), 0, ovc_hip_stream(stream),
-                       x, 1, 0L, nullptr, residual, gamma, beta, add, add_rows, zero_rows, eps, y, rows, d);
-    OVC_RETURN_IF_LAUNCH_FAILED();
-    return OVC_OK;
+    hipStream_t s = ovc_hip_stream(stream);
+    return residual ? launch_layer_norm<1, false, true>(x, 0L, nullptr, residual, gamma, beta, add, add_rows, zero_rows, eps, y, rows, d, s)
+                    : launch_layer_norm<1, false, false>(x, 0L, nullptr, nullptr, gamma, beta, add, add_rows, zero_rows, eps, y, rows, d, s);
 }
 
 int ovc_layer_norm_parts(const float* parts, int nparts, long part_stride, const float* bias, const float* residual,
                          const float* gamma, const float* beta, const uint8_t* zero_rows, float eps, float* y,
                          int rows, int d, hipStream_t stream) {
-    if (!parts || nparts < 1 || !gamma || !beta || !y || rows <= 0 || d <= 0 || (d & 3) || d > 64 * 4 * kMaxVec) return OVC_EINVAL;
-    if ((part_stride & 3) || !ovc_aligned16(parts) || !ovc_aligned16(y) || (bias && !ovc_aligned16(bias)) ||
-        (residual && !ovc_aligned16(residual))) return OVC_EINVAL;
-    hipLaunchKernelGGL(layer_norm_rows, dim3((rows + 3) / 4), dim3(256), 0, stream,
-                       parts, nparts, part_stride, bias, residual, gamma, beta, nullptr, 0, zero_rows, eps, y, rows, d);
-    OVC_RETURN_IF_LAUNCH_FAILED();
-    return OVC_OK;
+    if (!parts || !bias || !residual || !gamma || !beta || !y || rows <= 0 || d <= 0 || (d & 3) || d > 64 * 4 * kMaxVec) return OVC_EINVAL;
+    if ((part_stride & 3) || !ovc_aligned16(parts) || !ovc_aligned16(y) || !ovc_aligned16(bias) || !ovc_aligned16(residual)) return OVC_EINVAL;
+    if (nparts == 2) return launch_layer_norm<2, true, true>(parts, part_stride, bias, residual, gamma, beta, nullptr, 0, zero_rows, eps, y, rows, d, stream);
+    if (nparts == 4) return launch_layer_norm<4, true, true>(parts, part_stride, bias, residual, gamma, beta, nullptr, 0, zero_rows, eps, y, rows, d, stream);
+    return OVC_EINVAL;
 }
 
 extern "C" int ovc_zero_row_mask(const float* x, int rows, int d, uint8_t* mask, ovc_stream stream) {

@@ -83,7 +83,8 @@ SIGNATURES = {
     "ovc_gated_accumulate": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_long, c_void_p]),
     "ovc_log_softmax": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "ovc_box_relation_weights": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
-    "ovc_beam_select": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "ovc_beam_select": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
+                                c_void_p, c_size_t, c_void_p]),
     "ovc_workspace_bytes": (c_size_t, [POINTER(Model), c_int, c_int, c_int, c_int]),
     "ovc_encode": (c_int, [POINTER(Model), c_void_p, c_void_p, c_int, c_int, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]),
     "ovc_beam_search": (c_int, [POINTER(Model), c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_size_t,

@@ -221,6 +221,7 @@ def beam_select(logp, running, alive, prev_words, eos_idx: int, k: int):
     chosen = torch.empty(B, k, dtype=torch.int64, device=logp.device)
     score = torch.empty(B, k, dtype=torch.float32, device=logp.device)
     masked = torch.empty_like(logp)
+    scratch = torch.empty(8 * B * width * k, dtype=torch.uint8, device=logp.device)
     check(lib.ovc_beam_select(_ptr(logp), _ptr(running_c), _ptr(alive_c), B, width, V, k, _ptr(chosen), _ptr(score),
-                              _ptr(masked), native.stream_handle()), "ovc_beam_select")
+                              _ptr(masked), _ptr(scratch), scratch.numel(), native.stream_handle()), "ovc_beam_select")
     return chosen, score, masked, alive

@@ -231,12 +231,18 @@ def test_beam_select(B, W, V, k):
     chosen = torch.empty(B, k, dtype=torch.int64, device=DEV)
     score = torch.empty(B, k, device=DEV)
     masked = torch.empty_like(lp)
-    rc = lib.ovc_beam_select(lp.data_ptr(), rn.data_ptr(), al.data_ptr(), B, W, V, k, chosen.data_ptr(),
-                             score.data_ptr(), masked.data_ptr(), native.stream_handle())
-    assert rc == 0
+    scratch = torch.empty(8 * B * W * k, dtype=torch.uint8, device=DEV)
+    args = (lp.data_ptr(), rn.data_ptr(), al.data_ptr(), B, W, V, k, chosen.data_ptr(), score.data_ptr())
+    assert lib.ovc_beam_select(*args, masked.data_ptr(), scratch.data_ptr(), scratch.numel(), native.stream_handle()) == 0
     np.testing.assert_array_equal(chosen.cpu().numpy(), want_idx.numpy())
     np.testing.assert_array_equal(score.cpu().numpy(), want_val.numpy())       # same fp32 expression: bit-exact
     np.testing.assert_array_equal(masked.cpu().numpy(), want_masked.numpy())
+    # without the masked log-probs a frozen beam's row is never read: same winners
+    chosen.zero_(); score.zero_()
+    assert lib.ovc_beam_select(*args, None, scratch.data_ptr(), scratch.numel(), native.stream_handle()) == 0
+    np.testing.assert_array_equal(chosen.cpu().numpy(), want_idx.numpy())
+    np.testing.assert_array_equal(score.cpu().numpy(), want_val.numpy())
+    assert lib.ovc_beam_select(*args, None, scratch.data_ptr(), scratch.numel() - 8, native.stream_handle()) == -2      # OVC_EWORKSPACE
 
 
 def test_beam_select_massive_ties_take_lowest_indices():
@@ -258,8 +264,9 @@ def test_beam_select_massive_ties_take_lowest_indices():
     lp, rn, al = d(logp), d(running), d(alive)
     chosen = torch.empty(B, k, dtype=torch.int64, device=DEV)
     score = torch.empty(B, k, device=DEV)
+    scratch = torch.empty(8 * B * W * k, dtype=torch.uint8, device=DEV)
     assert lib.ovc_beam_select(lp.data_ptr(), rn.data_ptr(), al.data_ptr(), B, W, V, k, chosen.data_ptr(),
-                               score.data_ptr(), None, native.stream_handle()) == 0
+                               score.data_ptr(), None, scratch.data_ptr(), scratch.numel(), native.stream_handle()) == 0
     np.testing.assert_array_equal(chosen.cpu().numpy(), want_idx.numpy())
     np.testing.assert_array_equal(score.cpu().numpy(), want_val.numpy())
     assert chosen[0].tolist() == [0, 1, 2, 3, 4] and chosen[1].tolist() == [2 * V + i for i in range(5)]
