@@ -276,6 +276,18 @@ __global__ __launch_bounds__(64) void beam_update_kernel(BeamUpdateArgs p) {
         p.lp_out[dst] = p.lp_in[src];
         p.anc_out[dst] = p.anc_in[src];
     }
+    // decoders.py:95-112 for the next step: token embedding + position t + 2 (running_seq counts from 1 and the
+    // next step is t + 1), and the <pad> flag of each row
+    if (p.next_x) {
+        const int nvec = p.d_model >> 2;
+        const f32x4* pos = reinterpret_cast<const f32x4*>(p.pos_emb + (size_t)(t + 2) * p.d_model);
+        for (int j = 0; j < k; ++j) {
+            const f32x4* e = reinterpret_cast<const f32x4*>(p.word_emb + (size_t)word[j] * p.d_model);
+            f32x4* o = reinterpret_cast<f32x4*>(p.next_x + ((size_t)b * k + j) * p.d_model);
+            for (int c = tid; c < nvec; c += 64) o[c] = e[c] + pos[c];
+        }
+        if (tid < k) p.next_padflag[b * k + tid] = word[tid] == p.pad ? 1 : 0;
+    }
 }
 
 // Final ordering (beam_search.py:97-113): beams sorted by total score, descending, stable.

@@ -134,6 +134,9 @@ struct BeamUpdateArgs {
     const int32_t* anc_in; int32_t* anc_out;        // [B*k, T] ancestor slots
     int32_t* next_tok;                              // [B*k]
     int width, k, V, T, t, eos;
+    // input rows of step t + 1, written here instead of by a separate launch (nullptr: not wanted):
+    //   next_x[b*k + j, :] = word_emb[word] + pos_emb[t + 2],  next_padflag[b*k + j] = (word == pad)
+    const float* word_emb; const float* pos_emb; float* next_x; uint8_t* next_padflag; int d_model, pad;
 };
 int ovc_beam_update_launch(const BeamUpdateArgs& p, int B, hipStream_t stream);
 

@@ -364,9 +364,11 @@ int run_decode_step(Engine& e, Workspace& w, int B, int N, int k, int t, int ret
     const int cur = t & 1, nxt = cur ^ 1;
     uint8_t* padflag_t = w.padflag + (size_t)t * R;
 
-    hipLaunchKernelGGL(decode_embed_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, w.tok, m->bos_idx, m->pad_idx, t,
-                       m->word_emb, m->pos_emb, w.x, padflag_t, rows, d);
-    OVC_RETURN_IF_LAUNCH_FAILED();
+    if (t == 0) {       // later steps: the previous step's update kernel has written the input rows and pad flags
+        hipLaunchKernelGGL(decode_embed_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, w.tok, m->bos_idx, m->pad_idx, t,
+                           m->word_emb, m->pos_emb, w.x, padflag_t, rows, d);
+        OVC_RETURN_IF_LAUNCH_FAILED();
+    }
 
     e.gemm_class = 2;
     float* x = w.x;
@@ -460,6 +462,10 @@ int run_decode_step(Engine& e, Workspace& w, int B, int N, int k, int t, int ret
     bu.hist_in = w.hist[cur]; bu.hist_out = w.hist[nxt]; bu.lp_in = w.lp[cur]; bu.lp_out = w.lp[nxt];
     bu.anc_in = w.anc[cur]; bu.anc_out = w.anc[nxt]; bu.next_tok = w.tok;
     bu.width = width; bu.k = k; bu.V = m->vocab; bu.T = T; bu.t = t; bu.eos = m->eos_idx;
+    if (t + 1 < T) {
+        bu.word_emb = m->word_emb; bu.pos_emb = m->pos_emb; bu.next_x = w.x; bu.next_padflag = w.padflag + (size_t)(t + 1) * R;
+        bu.d_model = d; bu.pad = m->pad_idx;
+    }
     return ovc_beam_update_launch(bu, B, s);
 }
 
