@@ -63,7 +63,8 @@ class Model(ctypes.Structure):
 ENC_PLAIN, ENC_MULTILEVEL, ENC_GEOMETRIC = 0, 1, 2
 DEC_PLAIN, DEC_MESHED = 0, 1
 
-LIBRARY_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libovc.so")
+# OVC_LIBRARY: load another build of the same ABI (A/B timing of kernel changes on one box)
+LIBRARY_PATH = os.environ.get("OVC_LIBRARY") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libovc.so")
 
 # name -> (restype, argtypes); exactly the entry points declared in include/ovc.h
 SIGNATURES = {
