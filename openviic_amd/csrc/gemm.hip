@@ -64,7 +64,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 }
 
 template <int BM, int BN, int WM, int WN, int WK, int BK>
-__global__ __launch_bounds__(256) void gemm_f32_mfma(GemmArgs p, int tiles_m, int tiles_n_per_seg, int group_m) {
+__global__ __launch_bounds__(256) void gemm_f32_mfma(GemmArgs p, int tiles_m, int tiles_n_per_seg, int group_m, int xcd_pm) {
     using Cfg = TileConfig<BM, BN, WM, WN, WK, BK>;
     constexpr int LDT = Cfg::LDT;
     constexpr int kVecPerRow = BK / 4;               // float4 per tile row
@@ -84,13 +84,26 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma(GemmArgs p, int tiles_m, in
     // used when all of A fits in L2 anyway.
     const int tile = xcd_remap(blockIdx.x, nwg);
     const int tiles_n_all = nwg / tiles_m;
-    const int group_size = group_m * tiles_n_all;
-    const int group = tile / group_size;
-    const int first_m = group * group_m;
-    const int gm = min(group_m, tiles_m - first_m);
-    const int in_group = tile - group * group_size;
-    const int tile_n_all = in_group / gm;
-    const int tile_m = first_m + (in_group - tile_n_all * gm);
+    int tile_m, tile_n_all;
+    if (xcd_pm > 0) {
+        // 2-D split of the tile grid over the 8 XCDs (xcd_pm x 8/xcd_pm sub-rectangles, M fastest inside): XCD L2s
+        // are private, so with a split along N only every XCD pulls all of A from the Infinity Cache (8 x 2.6 MB
+        // for the 1280-row decode products against 3.6 MB of operands); the host picks the split with the least
+        // total operand traffic.  Needs tiles_m % xcd_pm == 0 and tiles_n_all % (8 / xcd_pm) == 0.
+        const int per_chunk = nwg >> 3, chunk = tile / per_chunk, j = tile - chunk * per_chunk;
+        const int sub_m = tiles_m / xcd_pm, cm = chunk % xcd_pm, cn = chunk / xcd_pm;
+        const int sub_n = tiles_n_all / (8 / xcd_pm);
+        tile_m = cm * sub_m + j % sub_m;
+        tile_n_all = cn * sub_n + j / sub_m;
+    } else {
+        const int group_size = group_m * tiles_n_all;
+        const int group = tile / group_size;
+        const int first_m = group * group_m;
+        const int gm = min(group_m, tiles_m - first_m);
+        const int in_group = tile - group * group_size;
+        tile_n_all = in_group / gm;
+        tile_m = first_m + (in_group - tile_n_all * gm);
+    }
     const int seg = tile_n_all / tiles_n_per_seg;
     const int tile_n = tile_n_all - seg * tiles_n_per_seg;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
@@ -328,12 +341,25 @@ int launch_config(const GemmArgs& a, hipStream_t stream) {
     // A panel larger than ~3 MB cannot stay in a 4 MB L2: sweep it in super-rows of 8 M tiles
     const size_t a_bytes = sizeof(float) * (size_t)a.M * (a.K1 + a.K2);
     const int group_m = a_bytes <= (size_t)3 << 20 ? tiles_m : (tiles_m < 8 ? tiles_m : 8);
+    // operands that fit the L2s: 2-D XCD split with the least Infinity-Cache traffic  pn * |A| + pm * |W|
+    int xcd_pm = 0;
+    const int slices = a.ksplit > 1 ? a.ksplit : 1;         // K slices run one after the other (gridDim.y is the slow index)
+    if (a_bytes / slices <= (size_t)3 << 20) {
+        const size_t w_bytes = sizeof(float) * (size_t)a.seg_n * a.nseg * (a.K1 + a.K2);
+        const int tiles_n_all = tiles_n * a.nseg;
+        size_t best = 8 * a_bytes + w_bytes;                 // a split along N only (pm = 1): the plain tile order
+        for (int pm = 2; pm <= 8; pm *= 2) {
+            if (tiles_m % pm || tiles_n_all % (8 / pm)) continue;
+            const size_t cost = (size_t)(8 / pm) * a_bytes + (size_t)pm * w_bytes;
+            if (cost < best) { best = cost; xcd_pm = pm; }
+        }
+    }
     const dim3 grid3(grid, a.ksplit > 1 ? a.ksplit : 1);
     if (g_launch_start && g_launch_stop)
         hipExtLaunchKernelGGL((gemm_f32_mfma<BM, BN, WM, WN, WK, BK>), grid3, dim3(256), (uint32_t)lds_bytes, stream,
-                              g_launch_start, g_launch_stop, 0, a, tiles_m, tiles_n, group_m);
+                              g_launch_start, g_launch_stop, 0, a, tiles_m, tiles_n, group_m, xcd_pm);
     else
-        hipLaunchKernelGGL((gemm_f32_mfma<BM, BN, WM, WN, WK, BK>), grid3, dim3(256), lds_bytes, stream, a, tiles_m, tiles_n, group_m);
+        hipLaunchKernelGGL((gemm_f32_mfma<BM, BN, WM, WN, WK, BK>), grid3, dim3(256), lds_bytes, stream, a, tiles_m, tiles_n, group_m, xcd_pm);
     OVC_RETURN_IF_LAUNCH_FAILED();
     return OVC_OK;
 }
