@@ -273,7 +273,8 @@ __global__ __launch_bounds__(256) void decode_self_attention_kernel(DecodeSelfAr
     const int col = tid % cols, g = tid / cols;
     const int hd = (col * 4) / p.dv;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    const int nkeys = (t - g + groups) / groups;     // keys g, g+groups, ... <= t  (0 when g > t)
+    // keys g, g+groups, ... <= t (0 when g > t); threads past the last whole key group (256 % cols != 0) idle
+    const int nkeys = g < groups ? (t - g + groups) / groups : 0;
     for (int i0 = 0; i0 < nkeys; i0 += 4) {
         f32x4 v4[4];
         int jj[4];
@@ -298,7 +299,7 @@ int ovc_decode_self_attention(const DecodeSelfArgs& p, int rows, hipStream_t str
     const int hk = p.h * p.dk;
     if (p.t < 0 || p.t >= 64 || p.h <= 0 || p.h > kSelfMaxHeads) return OVC_EINVAL;
     if (p.dk != p.dv || (p.dk & (p.dk - 1)) || p.dk < 4 || p.dk > 64) return OVC_EINVAL;   // dk in {4,8,16,32,64}
-    if (hk > 1024 || 256 % (hk >> 2)) return OVC_EINVAL;                                   // h*dk in {64,128,256,512,1024}
+    if (hk > 1024) return OVC_EINVAL;
     if (hk <= 256) hipLaunchKernelGGL(decode_self_attention_kernel<1>, dim3(rows), dim3(256), 0, stream, p);
     else if (hk <= 512) hipLaunchKernelGGL(decode_self_attention_kernel<2>, dim3(rows), dim3(256), 0, stream, p);
     else hipLaunchKernelGGL(decode_self_attention_kernel<4>, dim3(rows), dim3(256), 0, stream, p);

@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import (FULL, TINY, TINY_SHAPE, VARIANTS, assert_ids_match_where_decided, batch, device_model, full_case,
+from helpers import (FULL, TINY, TINY_SHAPE, VARIANTS, assert_ids_match_where_decided, batch, decided_images, device_model, full_case,
                      golden, teacher_tokens, tiny_case)
 from oracle.captioner import OracleCaptioner
 
@@ -323,3 +323,47 @@ def test_k_split_projections_against_reference_golden(split):
     _logp_close(logp.cpu().numpy()[same], g[p + "logp"][same], "k-split logp")
     assert lib.ovc_gemm_tuned_set(16, 512, 1, 2048, 3 | 8 << 8 | 3 << 16) != 0      # more than 4 slices: refused
     assert lib.ovc_gemm_tuned_set(16, 512, 3, 2048, 3 | 2 << 8 | 3 << 16) != 0      # segmented outputs cannot split
+
+
+DIMS = [
+    # variant, model dims, (B, N, V, T, k)
+    ("standard_transformer", dict(d_feature=64, d_model=256, heads=4, d_kv=64, d_ff=512, layers=1), (3, 128, 300, 12, 3)),   # N at the engine's limit
+    ("standard_transformer", dict(d_feature=40, d_model=128, heads=8, d_kv=16, d_ff=256, layers=4), (2, 65, 16384, 5, 4)),   # V at the selection limit, d_k=16
+    ("standard_transformer", dict(d_feature=32, d_model=64, heads=2, d_kv=32, d_ff=128, layers=8), (2, 9, 97, 64, 2)),      # 8 layers, max_len = 64, d_k=32
+    ("meshed_memory_transformer", dict(d_feature=48, d_model=128, heads=2, d_kv=64, d_ff=256, layers=4, memory=7), (2, 20, 211, 6, 3)),  # 4 levels
+    ("object_relation_transformer", dict(d_feature=32, d_model=192, heads=3, d_kv=64, d_ff=384, layers=2), (2, 33, 150, 6, 3)),          # 3 heads
+    ("attention_on_attention", dict(d_feature=32, d_model=128, heads=4, d_kv=32, d_ff=256, layers=2), (3, 17, 131, 7, 5)),
+]
+
+
+@pytest.mark.parametrize("variant,dims,shape", DIMS, ids=[d[0] + "-" + "x".join(map(str, d[2])) for d in DIMS])
+def test_unusual_dimensions_against_oracle(variant, dims, shape):
+    """Architecture sizes away from the BASELINE ones, each at a limit of the engine (N = 128 regions, V = 16384
+    words, max_len = 64, 8 layers, 4 meshed levels, d_k in {16, 32, 64}, head counts that are not powers of two)."""
+    from openviic_amd.config import model_config
+    from openviic_amd.utils.synthetic import SyntheticVocab, synthetic_boxes, synthetic_features, synthetic_state_dict
+    from openviic_amd.builders import build_model
+    B, N, V, T, k = shape
+    vocab = SyntheticVocab(V, T)
+    cfg = model_config(variant, device="cpu", **dims)
+    sd = synthetic_state_dict(build_model(cfg, vocab).state_dict(), seed=77, mode="generic",
+                              memory_dims=(dims["d_kv"], dims.get("memory", 40)))
+    feats = synthetic_features(B, N, dims["d_feature"], seed=B + N, ragged=True)
+    boxes = synthetic_boxes(B, N, seed=N) if variant == "object_relation_transformer" else None
+    orc = OracleCaptioner(cfg, sd, V, T)
+    rec = {}
+    want_ids, want_logp = orc.beam_search(feats, k, out_size=k, boxes=boxes, record=rec)
+    model = device_model(cfg, vocab, sd)
+    with torch.no_grad():
+        ids, logp = model.beam_search(batch(feats, boxes), batch_size=B, beam_size=k, out_size=k)
+        enc, mask = model.encoder_forward(batch(feats, boxes))
+    want_enc, want_mask = orc.encode(feats, boxes)
+    assert torch.equal(mask.cpu(), want_mask)
+    np.testing.assert_allclose(enc.cpu().numpy(), want_enc.numpy(), rtol=2e-4, atol=2e-5)
+    gaps, inner = torch.stack(rec["gap"]).numpy(), torch.stack(rec["inner_gap"]).numpy()
+    decided = decided_images(gaps, inner, MARGIN)
+    if k > 1:
+        decided &= inner[-1].min(axis=1) > MARGIN                    # out_size = k: the whole final order counts
+    assert decided.any()
+    np.testing.assert_array_equal(ids.cpu().numpy()[decided], want_ids.numpy()[decided])
+    _logp_close(logp.cpu().numpy()[decided], want_logp.numpy()[decided], variant)
