@@ -164,7 +164,14 @@ typedef struct {
     const float* fc;                  /* decoder.fc.weight [V, d] (no bias)                 */
 } ovc_model;
 
-/* Bytes of scratch the engine needs for batch B, N regions, beam k (return_probs adds the
+/* Sizes the engine accepts (anything else: ovc_workspace_bytes returns 0, the calls OVC_EINVAL) -- the
+ * reference itself has no such limits, these are the template instances built so far:
+ *   regions N <= 128;  beam k <= OVC_MAX_BEAM (8);  max_len <= 64;  vocabulary <= 16384 words;
+ *   d_model <= 2048 (multiple of 4);  d_k, d_v <= 64 (multiples of 4), heads*d_k == heads*d_v, a multiple
+ *   of 64 and <= 1024;  layers <= OVC_MAX_LAYERS (8);  meshed levels <= OVC_MAX_LEVELS (4).
+ * tests/test_engine_gpu.py::test_unusual_dimensions_against_oracle runs each limit against the CPU oracle.
+ *
+ * Bytes of scratch the engine needs for batch B, N regions, beam k (return_probs adds the
  * [B,k,T,V] buffer).  0 on invalid arguments. */
 size_t ovc_workspace_bytes(const ovc_model* m, int B, int N, int k, int return_probs);
 
