@@ -9,7 +9,10 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int BM = 128, BN = 128, BK = 32;
 constexpr int kTileFloats = (BM + BN) * BK;          // one ring slot: A image then B image, rows of 32 floats, no padding
-constexpr int kSlots = 3;
+#ifndef SLOTS
+#define SLOTS 3
+#endif
+constexpr int kSlots = SLOTS;      // ring depth: SLOTS - 1 tiles in flight; 3 slots = 96 KB (1 workgroup per CU), 2 slots = 64 KB (2 per CU)
 
 __device__ __forceinline__ void glds16(const float* gsrc, float* lds_dst) {
     __builtin_amdgcn_global_load_lds(gsrc, (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
@@ -39,14 +42,13 @@ __global__ __launch_bounds__(256) void gemm_dma(const float* __restrict__ A, con
 
     f32x16 acc[2][2];
     for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    issue(0);
-    if (nkt > 1) issue(1);
+    for (int s = 0; s < kSlots - 1 && s < nkt; ++s) issue(s);
     const int frow = lane & 31, half = lane >> 5;
     for (int kt = 0; kt < nkt; ++kt) {
-        if (kt + 1 < nkt) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // tile kt landed, tile kt+1 may still fly
+        if (kSlots > 2 && kt + 1 < nkt) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // tile kt landed, tile kt+1 may still fly
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        if (kt + 2 < nkt) issue(kt + 2);
+        if (kt + kSlots - 1 < nkt) issue(kt + kSlots - 1);
         const float* slot = lds + (kt % kSlots) * kTileFloats;
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
