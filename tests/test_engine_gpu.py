@@ -367,3 +367,23 @@ def test_unusual_dimensions_against_oracle(variant, dims, shape):
     assert decided.any()
     np.testing.assert_array_equal(ids.cpu().numpy()[decided], want_ids.numpy()[decided])
     _logp_close(logp.cpu().numpy()[decided], want_logp.numpy()[decided], variant)
+
+
+def test_grid_feature_architecture_reads_grid_features():
+    """``StandardTransformerUsingGrid`` (standard_stransformer.py:45-68) is the region model fed from
+    ``grid_features``: same weights + same tensor under the other field name -> same captions."""
+    from openviic_amd.builders import build_model
+    from openviic_amd.config import model_config
+    cfg, vocab, sd, feats, _ = tiny_case("standard_transformer")
+    region = device_model(cfg, vocab, sd)
+    grid_cfg = model_config("standard_transformer_using_grid", device="cuda", **TINY)
+    grid = build_model(grid_cfg, vocab).eval()
+    grid.load_state_dict(sd, strict=False)
+    with torch.no_grad():
+        want = region.beam_search(batch(feats), batch_size=feats.shape[0], beam_size=3)
+        got = grid.beam_search(batch(feats, field="grid_features"), batch_size=feats.shape[0], beam_size=3)
+        logp = grid(batch(feats, tokens=teacher_tokens(feats.shape[0], TINY_SHAPE["T"], TINY_SHAPE["V"], seed=5), field="grid_features"))
+        ref = region(batch(feats, tokens=teacher_tokens(feats.shape[0], TINY_SHAPE["T"], TINY_SHAPE["V"], seed=5)))
+    assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1]) and torch.equal(logp, ref)
+    with pytest.raises((KeyError, AttributeError)):
+        grid.beam_search(batch(feats), batch_size=feats.shape[0], beam_size=3)      # no grid_features in the batch
