@@ -196,31 +196,40 @@ __global__ __launch_bounds__(kSelThreads) void beam_row_select_kernel(BeamSelect
     }
     __syncthreads();
     const int nsurv = count;
+    if (nsurv > kSurvivorCap) {
+        // Massive ties (a live beam fed <pad> yields a uniform row: V equal scores; a frozen row when all
+        // log-probs are wanted).  Rare, so it is written for few registers rather than speed -- the register peak
+        // of this kernel decides whether all B*k workgroups are resident at once: k rounds of a block-wide argmax
+        // over the candidates that come after the previous pick in the (score desc, index asc) order.
+        float pv = INFINITY;
+        int pi = -1;
+        for (int round = 0; round < k; ++round) {
+            Cand c; c.v = -INFINITY; c.idx = 0x7fffffff;
+#pragma unroll
+            for (int j = 0; j < kElems; ++j) {
+                const int col = kVec * (tid + (j / kVec) * kSelThreads) + (j % kVec);
+                const int idx = i * V + col;
+                const bool after = xv[j] < pv || (xv[j] == pv && idx > pi);
+                if (col < V && after && better(xv[j], idx, c.v, c.idx)) { c.v = xv[j]; c.idx = idx; }
+            }
+            c = wave_best(c);
+            __syncthreads();                   // the previous round's (or the survivor list's) readers are done
+            if (lane == 0) { surv_v[wave] = c.v; surv_i[wave] = c.idx; }
+            __syncthreads();
+            pv = surv_v[0]; pi = surv_i[0];
+#pragma unroll
+            for (int w = 1; w < kWaves; ++w)
+                if (better(surv_v[w], surv_i[w], pv, pi)) { pv = surv_v[w]; pi = surv_i[w]; }
+            if (tid == 0) { cand_v[round] = pv; cand_i[round] = pi; }
+        }
+        return;
+    }
+    if (wave != 0) return;
     float mv[kMaxK];
     int mi[kMaxK];
 #pragma unroll
     for (int s = 0; s < kMaxK; ++s) { mv[s] = -INFINITY; mi[s] = 0x7fffffff; }
-    if (nsurv <= kSurvivorCap) {
-        if (wave != 0) return;
-        for (int e = lane; e < nsurv; e += 64) list_insert(mv, mi, k, surv_v[e], surv_i[e]);
-    } else {
-        // Massive ties (a live beam fed <pad> yields a uniform row: V equal scores; a frozen row when all
-        // log-probs are wanted).  Exhaustive path: per-lane sorted lists over all candidates, wave top-k, merged
-        // by wave 0.
-#pragma unroll
-        for (int j = 0; j < kElems; ++j) {
-            const int c = kVec * (tid + (j / kVec) * kSelThreads) + (j % kVec);
-            if (c < V && better(xv[j], i * V + c, mv[k - 1], mi[k - 1])) list_insert(mv, mi, k, xv[j], i * V + c);
-        }
-        const Cand wbest = wave_topk(mv, mi, k, lane);
-        __syncthreads();                       // the survivor list is dead: reuse its head as the merge buffer
-        if (lane < k) { surv_v[wave * k + lane] = wbest.v; surv_i[wave * k + lane] = wbest.idx; }
-        __syncthreads();
-        if (wave != 0) return;
-#pragma unroll
-        for (int s = 0; s < kMaxK; ++s) { mv[s] = -INFINITY; mi[s] = 0x7fffffff; }
-        for (int e = lane; e < kWaves * k; e += 64) list_insert(mv, mi, k, surv_v[e], surv_i[e]);
-    }
+    for (int e = lane; e < nsurv; e += 64) list_insert(mv, mi, k, surv_v[e], surv_i[e]);
     const Cand best = wave_topk(mv, mi, k, lane);
     if (lane < k) { cand_v[lane] = best.v; cand_i[lane] = best.idx; }
 }
