@@ -225,6 +225,12 @@ const char* ovc_profile_kernel_name(int tiling);   /* "" past the last tiling */
 int ovc_gemm_tune(int M, int seg_n, int nseg, int K, void* scratch, size_t scratch_bytes,
                   ovc_stream stream);
 
+/* What ovc_gemm_tune minimises: the time of `copies` identical products co-running in one launch (1..8).
+ * 1 (default) ranks tilings by isolated latency, which favours many small tiles; with several independent
+ * batches in flight on different streams, rank with copies = that number: fewer, larger tiles then win
+ * because they spend fewer CU-seconds and less L2 traffic per FLOP.  Affects later ovc_gemm_tune calls. */
+int ovc_gemm_tune_objective(int copies);
+
 /* Read / preset the remembered choice of a shape (-1 = not tuned): lets a host persist tuning results.
  * The value is  tiling | split << 8 | split_tiling << 16  (split 1: no K split, split_tiling 0). */
 int ovc_gemm_tuned_get(int M, int seg_n, int nseg, int K);

@@ -324,6 +324,10 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma(GemmArgs p, int tiles_m, in
 // Optional kernel-scoped timing events of the next launch (set by ovc_gemm_launch_timed): with them the launch
 // goes through hipExtLaunchKernelGGL, whose events take the dispatch packet's own begin / end timestamps.
 hipEvent_t g_launch_start = nullptr, g_launch_stop = nullptr;
+// Tuner only: gridDim.z identical copies of the product in one launch (the kernel ignores blockIdx.z), a proxy for
+// "this many batches in flight" that needs no extra streams and no host work between the copies.
+int g_launch_copies = 1;
+int g_tune_copies = 1;      // objective of ovc_gemm_tune: 1 = isolated latency, c > 1 = time of c co-running copies
 
 template <int BM, int BN, int WM, int WN, int WK, int BK>
 int launch_config(const GemmArgs& a, hipStream_t stream) {
@@ -354,7 +358,7 @@ int launch_config(const GemmArgs& a, hipStream_t stream) {
             if (cost < best) { best = cost; xcd_pm = pm; }
         }
     }
-    const dim3 grid3(grid, a.ksplit > 1 ? a.ksplit : 1);
+    const dim3 grid3(grid, a.ksplit > 1 ? a.ksplit : 1, g_launch_copies);
     if (g_launch_start && g_launch_stop)
         hipExtLaunchKernelGGL((gemm_f32_mfma<BM, BN, WM, WN, WK, BK>), grid3, dim3(256), (uint32_t)lds_bytes, stream,
                               g_launch_start, g_launch_stop, 0, a, tiles_m, tiles_n, group_m, xcd_pm);
@@ -522,6 +526,7 @@ extern "C" int ovc_gemm_tune(int M, int seg_n, int nseg, int K, void* scratch, s
     if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return OVC_ELAUNCH;
     const int saved = g_forced_tiling;
     int rc = OVC_OK;
+    g_launch_copies = g_tune_copies;
     // fastest tiling of `a` (plain or K-split), -1 when nothing fits
     auto fastest = [&](const GemmArgs& g, float* best_ms) {
         int best = -1;
@@ -556,9 +561,16 @@ extern "C" int ovc_gemm_tune(int M, int seg_n, int nseg, int K, void* scratch, s
         if (t >= 0 && ms < split_ms) { split_ms = ms; split = s; split_tiling = t; }
     }
     g_forced_tiling = saved;
+    g_launch_copies = 1;
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     if (rc != OVC_OK) return rc;
     if (plain >= 0) g_tuned.push_back(TunedShape{M, seg_n, nseg, K, plain, split, split_tiling});
+    return OVC_OK;
+}
+
+extern "C" int ovc_gemm_tune_objective(int copies) {
+    if (copies < 1 || copies > 8) return OVC_EINVAL;
+    g_tune_copies = copies;
     return OVC_OK;
 }
 
