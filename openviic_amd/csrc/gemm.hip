@@ -17,11 +17,16 @@
 //   * 256 threads = 4 waves = one wave per SIMD; LDS double-buffered with one barrier per
 //     32-deep K tile; the next tile's global loads are issued before the MFMA block and written
 //     to LDS after it (issue-early / write-late).
-//   * blockIdx is remapped so that the 8 XCDs each walk a contiguous range of N tiles with all
-//     M tiles of a given N tile adjacent: a weight tile is fetched from HBM once per XCD and
-//     re-used from that XCD's L2 by the other M tiles.
+//   * blockIdx is remapped so that each of the 8 XCDs (private L2s) works on a contiguous part of the tile
+//     grid: super-rows of 8 M tiles swept over N when the A panel exceeds L2, otherwise a 2-D split
+//     pm x 8/pm chosen on the host to minimise the operand bytes the XCDs pull from the Infinity Cache.
 //   * Segments: N may be split into up to 8 equal segments with their own weight / bias /
 //     output pointers (fused q|k|v projections writing straight into the K/V caches).
+//   * K split across workgroups (gridDim.y slices writing raw partial products that the consuming
+//     LayerNorm sums in order) for the M = B*k products back to d_model, whose 32x32 tiles are bound by
+//     the CU's L2 port rather than by the matrix cores.
+//   * Twelve tilings (128x128 ... 32x32 with a 4-way K split inside the workgroup; K tile 32 or 64);
+//     ovc_gemm_tune measures them per shape, a cost model covers shapes that were never measured.
 #include <vector>
 
 #include <hip/hip_ext.h>
