@@ -322,3 +322,45 @@ def test_dlct_encoder_full_size_against_oracle(trig):
     assert torch.equal(r2a.cpu(), or2a) and torch.equal(g2a.cpu(), og2a) and torch.equal(mask.cpu(), want_mask)
     assert orm.any() and not orm.all()
     _close(out, want, tol=1e-4, what="DLCT encoder (full size)")
+
+
+def test_beam_select_random_shapes():
+    """Selection against torch's stable sort on 40 seeded random shapes: widths 1..8, beams 1..8, vocabularies
+    from 9 to 16384 words (every template instance of the row kernel), random frozen beams, planted exact ties."""
+    from openviic_amd import native
+    lib = native.load()
+    rng = np.random.default_rng(2024)
+    for case in range(40):
+        W = int(rng.integers(1, 9))
+        k = int(rng.integers(1, 9))
+        V = int(rng.choice([9, 40, 257, 1000, 1024, 1025, 4096, 4100, 10201, 10240, 16384]))
+        B = int(rng.integers(1, 6))
+        if W * V < k:
+            continue
+        g = torch.Generator().manual_seed(1000 + case)
+        logp = torch.log_softmax(torch.randn(B, W, V, generator=g) * float(rng.uniform(0.5, 4.0)), -1)
+        running = torch.randn(B, W, generator=g) * 2
+        alive = (torch.rand(B, W, generator=g) > 0.3).float()
+        alive[:, 0] = 1
+        if V > 12:                                   # exact ties inside a row and across rows
+            logp[0, 0, 3] = logp[0, 0, 11] = logp[0, 0].max() + 0.25
+            if W > 1:
+                running[0, 1] = running[0, 0]
+                logp[0, 1] = logp[0, 0]
+                alive[0, 1] = 1
+        want_idx, want_val, want_masked = _select_ref(logp, running, alive, k)
+        d = lambda t: t.to(DEV).contiguous()
+        lp, rn, al = d(logp), d(running), d(alive)
+        chosen = torch.empty(B, k, dtype=torch.int64, device=DEV)
+        score = torch.empty(B, k, device=DEV)
+        masked = torch.empty_like(lp) if case % 2 else None
+        scratch = torch.empty(8 * B * W * k, dtype=torch.uint8, device=DEV)
+        rc = lib.ovc_beam_select(lp.data_ptr(), rn.data_ptr(), al.data_ptr(), B, W, V, k, chosen.data_ptr(), score.data_ptr(),
+                                 None if masked is None else masked.data_ptr(), scratch.data_ptr(), scratch.numel(),
+                                 native.stream_handle())
+        assert rc == 0, (case, B, W, V, k)
+        what = "case %d: B=%d W=%d V=%d k=%d" % (case, B, W, V, k)
+        np.testing.assert_array_equal(chosen.cpu().numpy(), want_idx.numpy(), err_msg=what)
+        np.testing.assert_array_equal(score.cpu().numpy(), want_val.numpy(), err_msg=what)
+        if masked is not None:
+            np.testing.assert_array_equal(masked.cpu().numpy(), want_masked.numpy(), err_msg=what)
