@@ -63,7 +63,7 @@ def test_linear_rejects_cpu_tensors():
         ops.linear(torch.randn(4, 8), torch.randn(8, 8))
 
 
-@pytest.mark.parametrize("d", [64, 512, 2048])
+@pytest.mark.parametrize("d", [4, 64, 192, 260, 512, 1000, 2048])       # 1, 2, 4 and 8 vectors per lane, ragged last vector
 def test_layer_norm(d):
     from openviic_amd import ops
     g = torch.Generator().manual_seed(d)
