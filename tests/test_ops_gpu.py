@@ -364,3 +364,25 @@ def test_beam_select_random_shapes():
         np.testing.assert_array_equal(score.cpu().numpy(), want_val.numpy(), err_msg=what)
         if masked is not None:
             np.testing.assert_array_equal(masked.cpu().numpy(), want_masked.numpy(), err_msg=what)
+
+
+@pytest.mark.parametrize("M,N,K", [(130, 200, 96), (65, 33, 36), (1280, 512, 512), (257, 1536, 128), (31, 10201, 64)])
+def test_linear_every_tiling(M, N, K):
+    """Every instance of the GEMM template on shapes with M / N tails and (K = 36) a K tail, bias + ReLU + residual
+    epilogue, against fp64; the forced-tiling hook is the one tools/gemm_bench.py uses."""
+    from openviic_amd import native, ops
+    lib = native.load()
+    g = torch.Generator().manual_seed(M + N + K)
+    x, w = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) / math.sqrt(K)
+    b, r = torch.randn(N, generator=g), torch.randn(M, N, generator=g)
+    want = torch.relu(x.double() @ w.double().T + b.double()) + r.double()
+    xd, wd, bd, rd = (t.to(DEV) for t in (x, w, b, r))
+    try:
+        t = 0
+        while lib.ovc_debug_force_gemm_tiling(t) == 0:
+            got = ops.linear(xd, wd, bd, relu=True, residual=rd)
+            _close(got, want, what="tiling %d on %dx%dx%d" % (t, M, N, K))
+            t += 1
+        assert t == 12
+    finally:
+        lib.ovc_debug_force_gemm_tiling(-1)
