@@ -64,6 +64,11 @@ def test_tiny_beam_search_fused(variant, trig, tag, k):
     np.testing.assert_array_equal(ids.cpu().numpy(), g["beam%d_ids" % k])     # tiny fixtures have wide margins
     _logp_close(logp.cpu().numpy(), g["beam%d_logp" % k], "beam log-probs")
     _logp_close(everything.cpu().numpy(), g["beam%d_all" % k], "return_probs tensor")
+    # without return_probs a frozen beam's logits are never read and no log-prob tensor is written: same captions
+    with torch.no_grad():
+        ids_t, logp_t = model.beam_search(items, batch_size=TINY_SHAPE["B"], beam_size=k, out_size=k)
+    np.testing.assert_array_equal(ids_t.cpu().numpy(), g["beam%d_ids" % k])
+    _logp_close(logp_t.cpu().numpy(), g["beam%d_logp" % k], "beam log-probs without return_probs")
     if k == 3:
         ids1, logp1 = model.beam_search(items, batch_size=TINY_SHAPE["B"], beam_size=k, out_size=1)
         assert tuple(ids1.shape) == (TINY_SHAPE["B"], TINY_SHAPE["T"])
@@ -103,6 +108,14 @@ def test_forced_eos_and_pad():
     assert (want[decided] == 2).sum() >= 3 and (want[decided] == 0).sum() >= 10
     _logp_close(logp.cpu().numpy()[decided], g["logp"][decided], "forced eos/pad log-probs")
     _logp_close(everything.cpu().numpy()[decided], g["all"][decided], "forced eos/pad return_probs")
+    # the same fixture without return_probs (frozen beams' rows skipped; <pad>-fed beams whose uniform rows take the
+    # exhaustive tie path): on the tie images both calls must agree with each other (lower flat index first),
+    # whatever the reference's unstable sort did
+    with torch.no_grad():
+        ids_t, logp_t = model.beam_search(batch(feats), batch_size=6, beam_size=3, out_size=3)
+    np.testing.assert_array_equal(ids_t.cpu().numpy()[decided], want[decided])
+    np.testing.assert_array_equal(ids_t.cpu().numpy(), got)
+    _logp_close(logp_t.cpu().numpy()[decided], g["logp"][decided], "forced eos/pad log-probs without return_probs")
 
 
 @pytest.mark.parametrize("variant", VARIANTS)
