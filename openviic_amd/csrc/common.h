@@ -35,6 +35,7 @@ struct GemmSegment {
     const float* W;      // [seg_n, K] row-major
     const float* bias;   // [seg_n] or nullptr
     float* C;            // [M, seg_n] with row stride ldc
+    const float* A2;     // this segment's own second input block [M, K2] (row stride lda2), or nullptr = GemmArgs::A2
 };
 
 struct GemmArgs {

@@ -421,12 +421,20 @@ int run_decode_step(Engine& e, Workspace& w, int B, int N, int k, int t, int ret
                     TRY(e.aoa(dl.cross_att, w.x1, w.enc_att + lvl * nrd, w.info, w.gate, rows));
                 }
             }
-            for (int lvl = 0; lvl < lv; ++lvl) {
+            // level gates alpha_l = W_l [x1 ; enc_att_l] + b_l (decoders.py:59-66): one launch, a segment per level,
+            // each with its own second input block (separate launches when the width does not align with the tiles)
+            {
                 GemmArgs g{};
-                g.A1 = w.x1; g.lda1 = d; g.K1 = d; g.A2 = w.enc_att + lvl * nrd; g.lda2 = d; g.K2 = d;
-                g.M = rows; g.seg_n = d; g.nseg = 1; g.ldc = d;
-                g.seg[0] = GemmSegment{dl.alpha[lvl].w, dl.alpha[lvl].b, w.alpha + lvl * nrd};
-                TRY(e.gemm(g));
+                g.A1 = w.x1; g.lda1 = d; g.K1 = d; g.lda2 = d; g.K2 = d;
+                g.M = rows; g.seg_n = d; g.ldc = d;
+                const bool fused = d % 64 == 0 && lv <= OVC_MAX_SEGMENTS;
+                for (int lvl = 0; lvl < lv; ++lvl) {
+                    GemmSegment seg{dl.alpha[lvl].w, dl.alpha[lvl].b, w.alpha + lvl * nrd, w.enc_att + lvl * nrd};
+                    if (fused) { g.seg[lvl] = seg; continue; }
+                    g.seg[0] = seg; g.nseg = 1;
+                    TRY(e.gemm(g));
+                }
+                if (fused) { g.nseg = lv; TRY(e.gemm(g)); }
             }
             TRY(ovc_meshed_mix(w.alpha, w.enc_att, lv, (long)nrd, sqrtf((float)lv), w.mixed, s));
             ffn_in = w.mixed;

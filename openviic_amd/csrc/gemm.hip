@@ -139,7 +139,8 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma(GemmArgs p, int tiles_m, in
     // vector instructions on addresses (+4..5 % on the 128x128 loop, tools/gemm_ablation.hip).  Rows past M / N
     // fall outside the descriptor's range and read as zero; a K tail is zeroed when the registers go to LDS.
     const __amdgpu_buffer_rsrc_t rsrc_a1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.A1), 0, p.M * p.lda1 * 4, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsrc_a2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.K2 ? p.A2 : p.A1), 0,
+    const float* a2 = p.seg[seg].A2 ? p.seg[seg].A2 : p.A2;       // per-segment second block (meshed level gates)
+    const __amdgpu_buffer_rsrc_t rsrc_a2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.K2 ? a2 : p.A1), 0,
                                                                               p.K2 ? p.M * p.lda2 * 4 : 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(W), 0, p.seg_n * K * 4, 0x00020000);
     int off_a1[Cfg::kLoadA], off_a2[Cfg::kLoadA], off_w[Cfg::kLoadB];
@@ -477,7 +478,12 @@ int ovc_gemm_launch(const GemmArgs& a, hipStream_t stream) {
     const int K = a.K1 + a.K2;
     if (a.M <= 0 || a.seg_n <= 0 || a.nseg <= 0 || a.nseg > OVC_MAX_SEGMENTS || K <= 0) return OVC_EINVAL;
     if ((a.K1 & 3) || (a.K2 & 3) || (a.lda1 & 3) || (a.K2 && (a.lda2 & 3))) return OVC_EINVAL;
-    if (!ovc_aligned16(a.A1) || (a.K2 && !ovc_aligned16(a.A2))) return OVC_EINVAL;
+    if (!ovc_aligned16(a.A1) || (a.K2 && !a.A2 && !a.seg[0].A2) || (a.A2 && !ovc_aligned16(a.A2))) return OVC_EINVAL;
+    for (int s = 0; s < a.nseg; ++s)
+        if (a.seg[s].A2 && (!a.K2 || !ovc_aligned16(a.seg[s].A2))) return OVC_EINVAL;
+    if (a.K2 && !a.A2)                                   // no shared second block: every segment brings its own
+        for (int s = 0; s < a.nseg; ++s)
+            if (!a.seg[s].A2) return OVC_EINVAL;
     if (a.R && a.nseg != 1) return OVC_EINVAL;
     if (a.K2 > 0 && (a.K1 % 32)) return OVC_EINVAL;      // the A1|A2 seam must fall on a K-tile boundary
     if (a.ksplit > 1) {                                  // raw partial products: see GemmArgs::ksplit

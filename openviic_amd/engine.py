@@ -131,7 +131,7 @@ class CaptionEngine:
             shapes.update({(rows, hk, 3, dm), (rows, dm, 1, hv), (rows, hk, 1, dm), (rows, ff, 1, dm),
                            (rows, dm, 1, ff), (rows, d.vocab, 1, dm)})
             if d.dec_kind == native.DEC_MESHED:
-                shapes.add((rows, dm, 1, 2 * dm))                    # level gates
+                shapes.add((rows, dm, d.n_levels if dm % 64 == 0 else 1, 2 * dm))      # level gates, one segment per level
                 shapes.add((rows * d.n_levels, dm, 1, hv))           # shared output projection over the stacked levels
         for rows, aoa in ((bn, self.model.encoder.layers[0].mhatt.use_aoa),
                           (B, self.model.decoder.layers[0].self_attn.use_aoa),
