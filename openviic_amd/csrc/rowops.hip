@@ -49,6 +49,14 @@ __global__ __launch_bounds__(256) void layer_norm_rows(const float* __restrict__
 #pragma unroll
         for (int i = 0; i < kVecs; ++i) rv[i] = reinterpret_cast<const f32x4*>(residual + (size_t)row * d)[col[i]];
     }
+    // gamma / beta do not depend on the row's moments: fetched now, not after them (one memory round trip less
+    // on a kernel that is nothing but a chain of them)
+    f32x4 gv[kVecs], bev[kVecs];
+#pragma unroll
+    for (int i = 0; i < kVecs; ++i) {
+        gv[i] = reinterpret_cast<const f32x4*>(gamma)[col[i]];
+        bev[i] = reinterpret_cast<const f32x4*>(beta)[col[i]];
+    }
     if (cleared) {
         for (int c = lane; c < nvec; c += 64) reinterpret_cast<f32x4*>(yrow)[c] = f32x4{0.f, 0.f, 0.f, 0.f};
         return;
@@ -79,7 +87,7 @@ __global__ __launch_bounds__(256) void layer_norm_rows(const float* __restrict__
     for (int i = 0; i < kVecs; ++i) {
         const int c = lane + i * 64;
         if (c < nvec) {
-            f32x4 o = (v[i] - mean) * rstd * reinterpret_cast<const f32x4*>(gamma)[c] + reinterpret_cast<const f32x4*>(beta)[c];
+            f32x4 o = (v[i] - mean) * rstd * gv[i] + bev[i];
             if (ar) o += ar[c];
             reinterpret_cast<f32x4*>(yrow)[c] = o;
         }
