@@ -166,7 +166,8 @@ typedef struct {
 
 /* Sizes the engine accepts (anything else: ovc_workspace_bytes returns 0, the calls OVC_EINVAL) -- the
  * reference itself has no such limits, these are the template instances built so far:
- *   regions N <= 128;  beam k <= OVC_MAX_BEAM (8);  max_len <= 64;  vocabulary <= 16384 words;
+ *   regions N <= 128;  beam k <= OVC_MAX_BEAM (8);  max_len <= 64;  any vocabulary (above 16384 words the
+ *   selection streams each row k + 2 times instead of holding it in registers);
  *   d_model <= 2048 (multiple of 4);  d_k, d_v <= 64 (multiples of 4), heads*d_k == heads*d_v, a multiple
  *   of 64 and <= 1024;  layers <= OVC_MAX_LAYERS (8);  meshed levels <= OVC_MAX_LEVELS (4).
  * tests/test_engine_gpu.py::test_unusual_dimensions_against_oracle runs each limit against the CPU oracle.

@@ -234,6 +234,69 @@ __global__ __launch_bounds__(kSelThreads) void beam_row_select_kernel(BeamSelect
     if (lane < k) { cand_v[lane] = best.v; cand_i[lane] = best.idx; }
 }
 
+// Any vocabulary size: the row is streamed from memory instead of held in registers -- one pass for the maximum,
+// one for the sum of exponentials (and the masked log-probs), then k rounds of a block-wide argmax over the
+// candidates that come after the previous pick in the (score desc, index asc) order.  k + 2 passes over the row:
+// used only for vocabularies beyond the register-resident instances above (V > 16384; 64 * 256 without 16-byte rows).
+__global__ __launch_bounds__(kSelThreads) void beam_row_select_streaming_kernel(BeamSelectArgs p) {
+    constexpr int kWaves = kSelThreads / 64;
+    __shared__ float red[kWaves];
+    __shared__ float pick_v[kWaves];
+    __shared__ int pick_i[kWaves];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int row = blockIdx.x, W = p.width, V = p.V, k = p.k, i = row % W;
+    const float run = p.running[row];
+    const float alive = p.alive ? p.alive[row] : 1.0f;
+    const bool live = alive != 0.0f;
+    const float* x = p.logits + (size_t)row * p.ld;
+    float* cand_v = p.cand_v + (size_t)row * k;
+    int* cand_i = p.cand_i + (size_t)row * k;
+    float mx = 0.f, ls = 0.f;
+    if (!p.is_logp) {
+        float m = -INFINITY;
+        for (int c = tid; c < V; c += kSelThreads) m = fmaxf(m, x[c]);
+        m = wave_max(m);
+        if (lane == 0) red[wave] = m;
+        __syncthreads();
+        m = red[0];
+        for (int w = 1; w < kWaves; ++w) m = fmaxf(m, red[w]);
+        mx = m;
+        float sum = 0.f;
+        for (int c = tid; c < V; c += kSelThreads) sum += __expf(x[c] - m);
+        sum = wave_sum(sum);
+        __syncthreads();
+        if (lane == 0) red[wave] = sum;
+        __syncthreads();
+        float tot = 0.f;
+        for (int w = 0; w < kWaves; ++w) tot += red[w];
+        ls = logf(tot);
+    }
+    if (tid == 0 && p.row_max_out) { p.row_max_out[row] = live ? mx : 0.f; p.row_lsum_out[row] = live ? ls : 0.f; }
+    if (p.masked_logp) {
+        float* mrow = p.masked_logp + (size_t)row * V;
+        for (int c = tid; c < V; c += kSelThreads) mrow[c] = ((x[c] - mx) - ls) * alive;
+    }
+    float pv = INFINITY;
+    int pi = -1;
+    for (int round = 0; round < k; ++round) {
+        Cand c; c.v = -INFINITY; c.idx = 0x7fffffff;
+        for (int col = tid; col < V; col += kSelThreads) {
+            const float cand = live ? run + ((x[col] - mx) - ls) : (col == 0 ? run : -999.0f);
+            const int idx = i * V + col;
+            const bool after = cand < pv || (cand == pv && idx > pi);
+            if (after && better(cand, idx, c.v, c.idx)) { c.v = cand; c.idx = idx; }
+        }
+        c = wave_best(c);
+        __syncthreads();
+        if (lane == 0) { pick_v[wave] = c.v; pick_i[wave] = c.idx; }
+        __syncthreads();
+        pv = pick_v[0]; pi = pick_i[0];
+        for (int w = 1; w < kWaves; ++w)
+            if (better(pick_v[w], pick_i[w], pv, pi)) { pv = pick_v[w]; pi = pick_i[w]; }
+        if (tid == 0) { cand_v[round] = pv; cand_i[round] = pi; }
+    }
+}
+
 // The k best of an image's width*k row candidates, in order; lane r < k of the (single) wave returns the r-th.
 __device__ __forceinline__ Cand merge_row_candidates(const float* cand_v, const int* cand_i, int b, int W, int k, int lane) {
     Cand c; c.v = -INFINITY; c.idx = 0x7fffffff;
@@ -346,17 +409,18 @@ int ovc_beam_select_launch(const BeamSelectArgs& p, int B, hipStream_t stream) {
     const dim3 grid(B * p.width), block(kSelThreads);
     const bool vec = (p.ld & 3) == 0 && ovc_aligned16(p.logits);
 #define OVC_SELECT(PT, VEC) hipLaunchKernelGGL((beam_row_select_kernel<PT, VEC>), grid, block, 0, stream, p)
+#define OVC_SELECT_STREAMING() hipLaunchKernelGGL(beam_row_select_streaming_kernel, grid, block, 0, stream, p)
     if (vec) {
         const int per_thread = (p.V + 4 * kSelThreads - 1) / (4 * kSelThreads);      // 16-byte loads
         if (per_thread <= 1) OVC_SELECT(1, 4); else if (per_thread <= 4) OVC_SELECT(4, 4);
-        else if (per_thread <= 10) OVC_SELECT(10, 4); else if (per_thread <= 16) OVC_SELECT(16, 4); else return OVC_EINVAL;
+        else if (per_thread <= 10) OVC_SELECT(10, 4); else if (per_thread <= 16) OVC_SELECT(16, 4); else OVC_SELECT_STREAMING();
     } else {
         const int per_thread = (p.V + kSelThreads - 1) / kSelThreads;
         if (per_thread <= 4) OVC_SELECT(4, 1); else if (per_thread <= 16) OVC_SELECT(16, 1);
-        else if (per_thread <= 40) OVC_SELECT(40, 1); else if (per_thread <= 64) OVC_SELECT(64, 1); else return OVC_EINVAL;
+        else if (per_thread <= 40) OVC_SELECT(40, 1); else if (per_thread <= 64) OVC_SELECT(64, 1); else OVC_SELECT_STREAMING();
     }
 #undef OVC_SELECT
-    // (vocabularies above 16384 words are not supported yet)
+#undef OVC_SELECT_STREAMING
     OVC_RETURN_IF_LAUNCH_FAILED();
     if (p.chosen) {
         hipLaunchKernelGGL(beam_merge_kernel, dim3(B), dim3(64), 0, stream, p);

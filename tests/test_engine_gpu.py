@@ -343,6 +343,7 @@ DIMS = [
     ("standard_transformer", dict(d_feature=64, d_model=256, heads=4, d_kv=64, d_ff=512, layers=1), (3, 128, 300, 12, 3)),   # N at the engine's limit
     ("standard_transformer", dict(d_feature=40, d_model=128, heads=8, d_kv=16, d_ff=256, layers=4), (2, 65, 16384, 5, 4)),   # V at the selection limit, d_k=16
     ("standard_transformer", dict(d_feature=32, d_model=64, heads=2, d_kv=32, d_ff=128, layers=8), (2, 9, 97, 64, 2)),      # 8 layers, max_len = 64, d_k=32
+    ("standard_transformer", dict(d_feature=32, d_model=64, heads=4, d_kv=16, d_ff=128, layers=1), (2, 5, 30011, 4, 3)),    # vocabulary beyond the register-resident selection
     ("meshed_memory_transformer", dict(d_feature=48, d_model=128, heads=2, d_kv=64, d_ff=256, layers=4, memory=7), (2, 20, 211, 6, 3)),  # 4 levels
     ("object_relation_transformer", dict(d_feature=32, d_model=192, heads=3, d_kv=64, d_ff=384, layers=2), (2, 33, 150, 6, 3)),          # 3 heads
     ("attention_on_attention", dict(d_feature=32, d_model=128, heads=4, d_kv=32, d_ff=256, layers=2), (3, 17, 131, 7, 5)),

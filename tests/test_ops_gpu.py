@@ -326,14 +326,14 @@ def test_dlct_encoder_full_size_against_oracle(trig):
 
 def test_beam_select_random_shapes():
     """Selection against torch's stable sort on 40 seeded random shapes: widths 1..8, beams 1..8, vocabularies
-    from 9 to 16384 words (every template instance of the row kernel), random frozen beams, planted exact ties."""
+    from 9 to 40003 words (every template instance of the row kernel and the streaming kernel), random frozen beams, planted exact ties."""
     from openviic_amd import native
     lib = native.load()
     rng = np.random.default_rng(2024)
     for case in range(40):
         W = int(rng.integers(1, 9))
         k = int(rng.integers(1, 9))
-        V = int(rng.choice([9, 40, 257, 1000, 1024, 1025, 4096, 4100, 10201, 10240, 16384]))
+        V = int(rng.choice([9, 40, 257, 1000, 1024, 1025, 4096, 4100, 10201, 10240, 16384, 16385, 20000, 40003]))
         B = int(rng.integers(1, 6))
         if W * V < k:
             continue
