@@ -341,7 +341,7 @@ def test_k_split_projections_against_reference_golden(split):
 DIMS = [
     # variant, model dims, (B, N, V, T, k)
     ("standard_transformer", dict(d_feature=64, d_model=256, heads=4, d_kv=64, d_ff=512, layers=1), (3, 128, 300, 12, 3)),   # N at the engine's limit
-    ("standard_transformer", dict(d_feature=40, d_model=128, heads=8, d_kv=16, d_ff=256, layers=4), (2, 65, 16384, 5, 4)),   # V at the selection limit, d_k=16
+    ("standard_transformer", dict(d_feature=40, d_model=128, heads=8, d_kv=16, d_ff=256, layers=4), (2, 65, 16384, 5, 4)),   # largest register-resident selection instance, d_k=16
     ("standard_transformer", dict(d_feature=32, d_model=64, heads=2, d_kv=32, d_ff=128, layers=8), (2, 9, 97, 64, 2)),      # 8 layers, max_len = 64, d_k=32
     ("standard_transformer", dict(d_feature=32, d_model=64, heads=4, d_kv=16, d_ff=128, layers=1), (2, 5, 30011, 4, 3)),    # vocabulary beyond the register-resident selection
     ("meshed_memory_transformer", dict(d_feature=48, d_model=128, heads=2, d_kv=64, d_ff=256, layers=4, memory=7), (2, 20, 211, 6, 3)),  # 4 levels
@@ -352,7 +352,7 @@ DIMS = [
 
 @pytest.mark.parametrize("variant,dims,shape", DIMS, ids=[d[0] + "-" + "x".join(map(str, d[2])) for d in DIMS])
 def test_unusual_dimensions_against_oracle(variant, dims, shape):
-    """Architecture sizes away from the BASELINE ones, each at a limit of the engine (N = 128 regions, V = 16384
+    """Architecture sizes away from the BASELINE ones, each at a limit of the engine or of a kernel instance (N = 128 regions, V = 16384 and 30011
     words, max_len = 64, 8 layers, 4 meshed levels, d_k in {16, 32, 64}, head counts that are not powers of two)."""
     from openviic_amd.config import model_config
     from openviic_amd.utils.synthetic import SyntheticVocab, synthetic_boxes, synthetic_features, synthetic_state_dict
