@@ -186,7 +186,7 @@ def g1_tiny(ref, out_dir, variant, trig=False, tag=None):
     print("wrote", name, {k: v.shape for k, v in data.items() if k.startswith("beam")})
 
 
-def g2_full(ref, out_dir, variant, batches=(4, 16)):
+def g2_full(ref, out_dir, variant, batches=(4, 16, 48)):
     V, T, N, D = 10201, 20, 50, 2048
     vocab = SyntheticVocab(V, T)
     cfg = model_config(variant, d_feature=D)
@@ -194,7 +194,7 @@ def g2_full(ref, out_dir, variant, batches=(4, 16)):
     boxes = variant == "object_relation_transformer"
     data = {}
     with torch.no_grad():
-        for B, k in [(batches[0], 1), (batches[0], 5), (batches[1], 5)]:
+        for B, k in [(batches[0], 1), (batches[0], 5), (batches[1], 5), (batches[2], 5)]:
             items = make_inputs(ref, B, N, D, seed=0, ragged=False, boxes=boxes)
             with SelectRecorder(ref) as rec:
                 ids, logp = model.beam_search(items, batch_size=B, beam_size=k, out_size=1)

@@ -120,11 +120,11 @@ def test_forced_eos_and_pad():
 
 @pytest.mark.parametrize("variant", VARIANTS)
 def test_full_size_against_reference_goldens(variant):
-    """BASELINE configs at d=512, N=50, d_feat=2048, V=10201, T=20: greedy B=4, beam-5 B=4 and B=16."""
+    """BASELINE configs at d=512, N=50, d_feat=2048, V=10201, T=20: greedy B=4, beam-5 B=4, B=16 and B=48."""
     g = golden("g2_full_%s.npz" % variant)
     model = None
     with torch.no_grad():
-        for B, k in [(4, 1), (4, 5), (16, 5)]:
+        for B, k in [(4, 1), (4, 5), (16, 5), (48, 5)]:
             cfg, vocab, sd, feats, boxes = full_case(variant, B)       # same generator calls as the golden run
             if model is None:
                 model = device_model(cfg, vocab, sd)
