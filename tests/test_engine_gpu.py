@@ -138,14 +138,20 @@ def test_full_size_against_reference_goldens(variant):
             assert same.mean() >= 0.9, "{}: only {:.0%} of images reproduce the reference ids".format(p, same.mean())
 
 
-def test_full_size_teacher_forced_forward():
-    g = golden("g2_full_standard_transformer.npz")
-    cfg, vocab, sd, feats, _ = full_case("standard_transformer", 4, ragged=True)
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_full_size_teacher_forced_forward(variant):
+    """Teacher-forced log-probs (sampled columns + per-position max / argmax) and encoder output of every variant at
+    full width on ragged inputs, against the reference."""
+    g = golden("g2_full_%s.npz" % variant)
+    cfg, vocab, sd, feats, boxes = full_case(variant, 4, ragged=True)
     model = device_model(cfg, vocab, sd)
     with torch.no_grad():
-        logp = model(batch(feats, tokens=torch.from_numpy(g["fwd_tokens"])))
-        enc, _ = model.encoder_forward(batch(feats))
+        logp = model(batch(feats, boxes, tokens=torch.from_numpy(g["fwd_tokens"])))
+        enc, _ = model.encoder_forward(batch(feats, boxes))
     _logp_close(logp[:, :, ::97].cpu().numpy(), g["fwd_sample"], "teacher-forced sample")
+    top, arg = logp.max(-1)
+    _logp_close(top.cpu().numpy(), g["fwd_max"], "teacher-forced maxima")
+    assert (arg.cpu().numpy() == g["fwd_argmax"]).mean() >= 0.99           # exact unless two words tie within fp32 noise
     np.testing.assert_allclose(enc.reshape(4, -1, enc.shape[-1])[:, ::7, ::5].cpu().numpy(), g["enc_sample"],
                                rtol=1e-3, atol=1e-4)
 
