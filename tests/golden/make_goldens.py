@@ -19,7 +19,8 @@ Fixture families:
       beam search with ``return_probs`` and ``out_size=k``
   G2  full-size configurations (d=512, N=50, d_feat=2048, V=10201, T=20): ids, log-probs and
       per-decision selection gaps for greedy / beam-5 decoding
-  G3  tiny configuration with a sharpened vocabulary projection that forces <eos> and <pad>
+  G3  tiny configuration with a sharpened vocabulary projection that forces <eos> and <pad> (standard and
+      meshed-memory decoders)
   G4  operator-level geometry cross-attention with nq != nk and a per-query mask (DLCT form)
   G5  box relation embedding for both ``trignometric_embedding`` values
   G6  ids -> caption strings through the reference's ``Vocab.decode_caption`` + duplicate collapse
@@ -215,14 +216,14 @@ def g2_full(ref, out_dir, variant, batches=(4, 16, 48)):
     print("wrote", name)
 
 
-def g3_forced(ref, out_dir):
+def g3_forced(ref, out_dir, variant="standard_transformer"):
     """<eos> and <pad> are (almost) never emitted under random weights; edit their rows.
 
     The edited ``decoder.fc.weight`` is stored in the fixture."""
     s = dict(TINY_SHAPE, B=6, T=8)
     vocab = SyntheticVocab(s["V"], s["T"])
-    cfg = model_config("standard_transformer", **TINY)
-    model = build_reference(ref, cfg, vocab, seed=21, mode="generic")
+    cfg = model_config(variant, **TINY)
+    model = build_reference(ref, cfg, vocab, seed=21, mode="generic", memory_dims=(TINY["d_kv"], TINY["memory"]))
     with torch.no_grad():
         w = model.decoder.fc.weight
         w[vocab.eos_idx] = 1.05 * w[8]       # <eos> tracks a frequently chosen word
@@ -237,8 +238,9 @@ def g3_forced(ref, out_dir):
     data.update(rec.arrays(""))
     n_eos, n_pad = int((ids == 2).sum()), int((ids == 0).sum())
     assert n_eos > 0 and n_pad > 0, (n_eos, n_pad)
-    np.savez_compressed(os.path.join(out_dir, "g3_forced_eos_pad.npz"), **data)
-    print("wrote g3_forced_eos_pad.npz  eos=%d pad=%d of %d" % (n_eos, n_pad, ids.numel()))
+    name = "g3_forced_eos_pad.npz" if variant == "standard_transformer" else "g3_forced_eos_pad_%s.npz" % variant
+    np.savez_compressed(os.path.join(out_dir, name), **data)
+    print("wrote %s  eos=%d pad=%d of %d" % (name, n_eos, n_pad, ids.numel()))
 
 
 def g4_dlct_operator(ref, out_dir):
@@ -425,6 +427,7 @@ def main():
         g1_tiny(ref, HERE, "object_relation_transformer", trig=True, tag="object_relation_transformer_trig")
     if on("g3"):
         g3_forced(ref, HERE)
+        g3_forced(ref, HERE, "meshed_memory_transformer")
     if on("g4"):
         g4_dlct_operator(ref, HERE)
     if on("g5"):

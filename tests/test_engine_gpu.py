@@ -90,10 +90,12 @@ def test_tiny_beam_search_host_loop_matches_fused(variant):
     assert model.decoder.running_seq.shape == (1,) and not model._is_stateful      # states reset on exit
 
 
-def test_forced_eos_and_pad():
+@pytest.mark.parametrize("variant,name,min_decided", [("standard_transformer", "g3_forced_eos_pad.npz", 3),
+                                                      ("meshed_memory_transformer", "g3_forced_eos_pad_meshed_memory_transformer.npz", 2)])
+def test_forced_eos_and_pad(variant, name, min_decided):
     """G3: finished beams (-999 branch) and <pad> emitted mid-sequence."""
-    g = golden("g3_forced_eos_pad.npz")
-    cfg, vocab, sd, feats, _ = tiny_case("standard_transformer", seed=21, feature_seed=8, B=6, T=8)
+    g = golden(name)
+    cfg, vocab, sd, feats, _ = tiny_case(variant, seed=21, feature_seed=8, B=6, T=8)
     sd["decoder.fc.weight"] = torch.from_numpy(g["decoder.fc.weight"])
     model = device_model(cfg, vocab, sd)
     with torch.no_grad():
@@ -103,9 +105,9 @@ def test_forced_eos_and_pad():
     # images without such ties are comparable (they still cover <eos> at several steps and <pad>).
     got, want = ids.cpu().numpy(), g["ids"]
     decided = np.asarray(g["gap"]).min(axis=0) > MARGIN
-    assert decided.sum() >= 3
+    assert decided.sum() >= min_decided
     np.testing.assert_array_equal(got[decided], want[decided])
-    assert (want[decided] == 2).sum() >= 3 and (want[decided] == 0).sum() >= 10
+    assert (want[decided] == 2).sum() >= 1 and (want[decided] == 0).sum() >= 10
     _logp_close(logp.cpu().numpy()[decided], g["logp"][decided], "forced eos/pad log-probs")
     _logp_close(everything.cpu().numpy()[decided], g["all"][decided], "forced eos/pad return_probs")
     # the same fixture without return_probs (frozen beams' rows skipped; <pad>-fed beams whose uniform rows take the

@@ -51,9 +51,11 @@ def test_tiny_beam_search(variant, trig, tag, k):
         np.testing.assert_allclose(logp1.numpy(), g["beam_out1_logp"], rtol=1e-5, atol=5e-6)
 
 
-def test_forced_eos_and_pad():
-    g = golden("g3_forced_eos_pad.npz")
-    cfg, vocab, sd, feats, _ = tiny_case("standard_transformer", seed=21, feature_seed=8, B=6, T=8)
+@pytest.mark.parametrize("variant,name", [("standard_transformer", "g3_forced_eos_pad.npz"),
+                                          ("meshed_memory_transformer", "g3_forced_eos_pad_meshed_memory_transformer.npz")])
+def test_forced_eos_and_pad(variant, name):
+    g = golden(name)
+    cfg, vocab, sd, feats, _ = tiny_case(variant, seed=21, feature_seed=8, B=6, T=8)
     sd["decoder.fc.weight"] = torch.from_numpy(g["decoder.fc.weight"])
     orc = _oracle(cfg, vocab, sd)
     rec = {}
