@@ -75,11 +75,11 @@ def test_tiny_beam_search_fused(variant, trig, tag, k):
         np.testing.assert_array_equal(ids1.cpu().numpy(), g["beam_out1_ids"])
 
 
-@pytest.mark.parametrize("variant", ["standard_transformer", "meshed_memory_transformer"])
-def test_tiny_beam_search_host_loop_matches_fused(variant):
+@pytest.mark.parametrize("variant,trig,tag", TINY_CASES)
+def test_tiny_beam_search_host_loop_matches_fused(variant, trig, tag):
     """step / statefulness / apply_to_states API (fused=False) gives the fused engine's result."""
-    g = golden("g1_tiny_%s.npz" % variant)
-    cfg, vocab, sd, feats, boxes = tiny_case(variant)
+    g = golden("g1_tiny_%s.npz" % tag)
+    cfg, vocab, sd, feats, boxes = tiny_case(variant, trig)
     model = device_model(cfg, vocab, sd)
     items = batch(feats, boxes)
     with torch.no_grad():
