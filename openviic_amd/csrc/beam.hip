@@ -327,7 +327,11 @@ __global__ __launch_bounds__(64) void beam_update_kernel(BeamUpdateArgs p) {
     __shared__ int parent[kMaxK], word[kMaxK];
     const Cand best = merge_row_candidates(p.cand_v, p.cand_i, b, W, k, tid);
     if (tid < k) {
-        const int f = best.idx;
+        // An image without a single valid region (all-zero features, e.g. the padding images of a ragged last shard)
+        // has every key masked: its logits are NaN, no candidate compares greater than anything and no winner
+        // exists.  The reference returns arbitrary in-range words for it; here slot j takes word j of beam 0, so
+        // that every index derived from it stays in range.
+        const int f = (unsigned)best.idx < (unsigned)(W * V) ? best.idx : tid;
         const int par = f / V, wd = f - par * V;
         parent[tid] = par; word[tid] = wd;
         const float alive = p.alive_in[b * W + par];

@@ -409,3 +409,19 @@ def test_grid_feature_architecture_reads_grid_features():
     assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1]) and torch.equal(logp, ref)
     with pytest.raises((KeyError, AttributeError)):
         grid.beam_search(batch(feats), batch_size=feats.shape[0], beam_size=3)      # no grid_features in the batch
+
+
+def test_image_without_regions_is_harmless():
+    """An all-zero feature block (the padding images ``decode_sharded`` appends to a ragged last shard) has every
+    attention key masked, so its logits are NaN and the reference returns arbitrary words for it.  The engine must
+    return in-range ids for it and leave the other images of the batch untouched."""
+    cfg, vocab, sd, feats, _ = tiny_case("standard_transformer")
+    model = device_model(cfg, vocab, sd)
+    padded = torch.cat([feats, torch.zeros_like(feats[:1])])
+    with torch.no_grad():
+        want, want_lp = model.beam_search(batch(feats), batch_size=feats.shape[0], beam_size=3)
+        got, got_lp = model.beam_search(batch(padded), batch_size=padded.shape[0], beam_size=3)
+        again, _ = model.beam_search(batch(feats), batch_size=feats.shape[0], beam_size=3)      # the engine is still usable
+    assert torch.equal(got[:-1], want) and torch.equal(again, want)
+    _logp_close(got_lp[:-1].cpu().numpy(), want_lp.cpu().numpy(), "other images next to an image without regions")   # other batch size, other tilings
+    assert got[-1].min() >= 0 and got[-1].max() < TINY_SHAPE["V"]
