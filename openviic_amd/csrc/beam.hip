@@ -313,7 +313,9 @@ __device__ __forceinline__ Cand merge_row_candidates(const float* cand_v, const 
 __global__ __launch_bounds__(64) void beam_merge_kernel(BeamSelectArgs p) {
     const Cand best = merge_row_candidates(p.cand_v, p.cand_i, blockIdx.x, p.width, p.k, threadIdx.x);
     if ((int)threadIdx.x < p.k) {
-        p.chosen[blockIdx.x * p.k + threadIdx.x] = (int64_t)best.idx;
+        // no winner at all (NaN scores: an image without valid regions): an in-range index, as in beam_update_kernel
+        const int idx = (unsigned)best.idx < (unsigned)(p.width * p.V) ? best.idx : (int)threadIdx.x;
+        p.chosen[blockIdx.x * p.k + threadIdx.x] = (int64_t)idx;
         p.score[blockIdx.x * p.k + threadIdx.x] = best.v;
     }
 }

@@ -386,3 +386,24 @@ def test_linear_every_tiling(M, N, K):
         assert t == 12
     finally:
         lib.ovc_debug_force_gemm_tiling(-1)
+
+
+def test_beam_select_with_nan_scores_returns_in_range_indices():
+    """NaN log-probs (an image whose every attention key is masked) have no order; the indices handed back must
+    still be usable as gather indices by the step-wise host loop."""
+    from openviic_amd import native
+    lib = native.load()
+    B, W, V, k = 2, 3, 200, 3
+    logp = torch.log_softmax(torch.randn(B, W, V, generator=torch.Generator().manual_seed(3)), -1)
+    logp[1] = float("nan")
+    running, alive = torch.zeros(B, W), torch.ones(B, W)
+    want_idx, want_val, _ = _select_ref(logp[:1], running[:1], alive[:1], k)
+    d = lambda t: t.to(DEV).contiguous()
+    lp, rn, al = d(logp), d(running), d(alive)
+    chosen = torch.empty(B, k, dtype=torch.int64, device=DEV)
+    score = torch.empty(B, k, device=DEV)
+    scratch = torch.empty(8 * B * W * k, dtype=torch.uint8, device=DEV)
+    assert lib.ovc_beam_select(lp.data_ptr(), rn.data_ptr(), al.data_ptr(), B, W, V, k, chosen.data_ptr(), score.data_ptr(),
+                               None, scratch.data_ptr(), scratch.numel(), native.stream_handle()) == 0
+    np.testing.assert_array_equal(chosen[:1].cpu().numpy(), want_idx.numpy())
+    assert chosen[1].min() >= 0 and chosen[1].max() < W * V
