@@ -84,9 +84,11 @@ int ovc_region_position_encoding(const uint8_t* mask, int b, int n, int d, float
                                  int normalize, float scale, float* pe, ovc_stream stream);
 
 /* y[r,:] = table[tokens[r],:] + pos_table[positions[r],:] (pos_table/positions may be NULL).
- * Replaces text_embeddings.py:28 and decoders.py:111-112. */
-int ovc_embed(const int64_t* tokens, const int64_t* positions, const float* table,
-              const float* pos_table, float* y, int rows, int d, ovc_stream stream);
+ * table has table_rows rows, pos_table pos_rows; an index outside its table reads the nearest valid row
+ * (nn.Embedding raises instead -- validate on the host where that matters; the device never reads out
+ * of bounds).  Replaces text_embeddings.py:28 and decoders.py:111-112. */
+int ovc_embed(const int64_t* tokens, const int64_t* positions, const float* table, int table_rows,
+              const float* pos_table, int pos_rows, float* y, int rows, int d, ovc_stream stream);
 
 /* y = a * sigmoid(g)  -- attentions.py:313-315. */
 int ovc_sigmoid_gate(const float* a, const float* g, float* y, long n, ovc_stream stream);

@@ -110,6 +110,7 @@ bool model_ok(const ovc_model* m) {
     if (m->d_k <= 0 || m->d_k > 64 || (m->d_k & 3) || m->d_v <= 0 || m->d_v > 64 || (m->d_v & 3)) return false;
     if ((m->d_feat & 3) || (m->d_ff & 3) || m->heads <= 0 || m->vocab <= 1) return false;
     if (m->max_len < 1 || m->max_len > 64) return false;
+    if (m->bos_idx < 0 || m->bos_idx >= m->vocab || m->pad_idx < 0 || m->pad_idx >= m->vocab || m->eos_idx < 0 || m->eos_idx >= m->vocab) return false;
     // fused q|k|v and cross k|v GEMMs need segment widths that are multiples of the 64-wide tile
     if ((m->heads * m->d_k) % 64 || (m->heads * m->d_v) % 64 || (m->heads * m->d_k) != (m->heads * m->d_v)) return false;
     if (m->dec_kind == OVC_DEC_MESHED && m->enc_kind != OVC_ENC_MULTILEVEL) return false;

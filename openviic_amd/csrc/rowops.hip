@@ -151,13 +151,20 @@ __global__ void region_pe_kernel(const uint8_t* __restrict__ mask, int b, int n,
 }
 
 __global__ __launch_bounds__(256) void embed_kernel(const int64_t* __restrict__ tokens, const int64_t* __restrict__ positions,
-                                                    const float* __restrict__ table, const float* __restrict__ pos_table,
+                                                    const float* __restrict__ table, int table_rows,
+                                                    const float* __restrict__ pos_table, int pos_rows,
                                                     float* __restrict__ y, int rows, int d) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
-    const f32x4* e = reinterpret_cast<const f32x4*>(table + (size_t)tokens[row] * d);
-    const f32x4* p = (pos_table && positions) ? reinterpret_cast<const f32x4*>(pos_table + (size_t)positions[row] * d) : nullptr;
+    // indices are clamped into their tables: a bad token id must not become a wild device read
+    const int64_t tok = min(max(tokens[row], (int64_t)0), (int64_t)table_rows - 1);
+    const f32x4* e = reinterpret_cast<const f32x4*>(table + (size_t)tok * d);
+    const f32x4* p = nullptr;
+    if (pos_table && positions) {
+        const int64_t pos = min(max(positions[row], (int64_t)0), (int64_t)pos_rows - 1);
+        p = reinterpret_cast<const f32x4*>(pos_table + (size_t)pos * d);
+    }
     f32x4* o = reinterpret_cast<f32x4*>(y + (size_t)row * d);
     for (int c = lane; c < (d >> 2); c += 64) o[c] = p ? e[c] + p[c] : e[c];
 }
@@ -303,12 +310,13 @@ extern "C" int ovc_region_position_encoding(const uint8_t* mask, int b, int n, i
     return OVC_OK;
 }
 
-extern "C" int ovc_embed(const int64_t* tokens, const int64_t* positions, const float* table,
-                         const float* pos_table, float* y, int rows, int d, ovc_stream stream) {
-    if (!tokens || !table || !y || rows <= 0 || d <= 0 || (d & 3)) return OVC_EINVAL;
+extern "C" int ovc_embed(const int64_t* tokens, const int64_t* positions, const float* table, int table_rows,
+                         const float* pos_table, int pos_rows, float* y, int rows, int d, ovc_stream stream) {
+    if (!tokens || !table || !y || rows <= 0 || d <= 0 || (d & 3) || table_rows <= 0) return OVC_EINVAL;
+    if (pos_table && positions && pos_rows <= 0) return OVC_EINVAL;
     if (!ovc_aligned16(table) || !ovc_aligned16(y) || (pos_table && !ovc_aligned16(pos_table))) return OVC_EINVAL;
     hipLaunchKernelGGL(embed_kernel, dim3((rows + 3) / 4), dim3(256), 0, ovc_hip_stream(stream), tokens, positions, table,
-                       pos_table, y, rows, d);
+                       table_rows, pos_table, pos_rows, y, rows, d);
     OVC_RETURN_IF_LAUNCH_FAILED();
     return OVC_OK;
 }

@@ -79,7 +79,7 @@ SIGNATURES = {
                               c_void_p, c_void_p]),
     "ovc_zero_row_mask": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "ovc_region_position_encoding": (c_int, [c_void_p, c_int, c_int, c_int, c_float, c_int, c_float, c_void_p, c_void_p]),
-    "ovc_embed": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "ovc_embed": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p]),
     "ovc_sigmoid_gate": (c_int, [c_void_p, c_void_p, c_void_p, c_long, c_void_p]),
     "ovc_gated_accumulate": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_long, c_void_p]),
     "ovc_log_softmax": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),

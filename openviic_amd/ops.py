@@ -154,11 +154,13 @@ def embed(tokens, table, positions=None, position_table=None):
     tokens = _dev(tokens, "tokens", torch.int64)
     table = _dev(table.detach(), "table")
     d = table.shape[1]
+    pos_rows = 0
     if positions is not None:
         positions = _dev(positions.expand_as(tokens), "positions", torch.int64)
         position_table = _dev(position_table.detach(), "position_table")
+        pos_rows = position_table.shape[0]
     y = torch.empty(*tokens.shape, d, dtype=torch.float32, device=tokens.device)
-    check(lib.ovc_embed(_ptr(tokens), _ptr(positions), _ptr(table), _ptr(position_table), _ptr(y),
+    check(lib.ovc_embed(_ptr(tokens), _ptr(positions), _ptr(table), table.shape[0], _ptr(position_table), pos_rows, _ptr(y),
                         tokens.numel(), d, native.stream_handle()), "ovc_embed")
     return y
 

@@ -407,3 +407,14 @@ def test_beam_select_with_nan_scores_returns_in_range_indices():
                                None, scratch.data_ptr(), scratch.numel(), native.stream_handle()) == 0
     np.testing.assert_array_equal(chosen[:1].cpu().numpy(), want_idx.numpy())
     assert chosen[1].min() >= 0 and chosen[1].max() < W * V
+
+
+def test_embed_clamps_indices_instead_of_reading_out_of_bounds():
+    from openviic_amd import ops
+    table = torch.randn(10, 8, generator=torch.Generator().manual_seed(1))
+    pos = torch.randn(4, 8, generator=torch.Generator().manual_seed(2))
+    tokens = torch.tensor([[0, 9, 10, 12345678901, -3]])
+    positions = torch.tensor([[0, 3, 4, 99, -1]])
+    got = ops.embed(tokens.to(DEV), table.to(DEV), positions.to(DEV), pos.to(DEV)).cpu()
+    want = table[tokens.clamp(0, 9)] + pos[positions.clamp(0, 3)]
+    np.testing.assert_array_equal(got.numpy(), want.numpy())
