@@ -20,6 +20,12 @@ def _dev(t: torch.Tensor, name: str, dtype=torch.float32) -> torch.Tensor:
     return t if t.is_contiguous() else t.contiguous()
 
 
+def _expect(t: torch.Tensor, shape, name: str) -> None:
+    """The kernels index with the caller's sizes: a tensor of another shape would be read out of bounds."""
+    if tuple(t.shape) != tuple(shape):
+        raise native.OvcError("{} must have shape {}; got {}".format(name, tuple(shape), tuple(t.shape)))
+
+
 def _ptr(t: Optional[torch.Tensor]):
     return None if t is None else t.data_ptr()
 
@@ -44,13 +50,17 @@ def linear(x, weight, bias=None, *, relu=False, residual=None, x2=None):
         x2 = _dev(x2, "x2")
         k2 = x2.shape[-1]
         x2_2d = x2.reshape(-1, k2)
+        _expect(x2_2d, (m, k2), "x2 (flattened)")
     n = weight.shape[0]
     if weight.shape[1] != k1 + k2:
         raise native.OvcError("weight is {} but inputs have {} features".format(tuple(weight.shape), k1 + k2))
     bias = None if bias is None else _dev(bias.detach(), "bias")
+    if bias is not None:
+        _expect(bias, (n,), "bias")
     res2d = None
     if residual is not None:
         res2d = _dev(residual, "residual").reshape(-1, n)
+        _expect(res2d, (m, n), "residual (flattened)")
     y = torch.empty(m, n, dtype=torch.float32, device=x.device)
     check(lib.ovc_linear(_ptr(x2d), k1, _ptr(x2_2d), k2, k1, k2, _ptr(weight), _ptr(bias), _ptr(res2d), n,
                          _ptr(y), n, m, n, 1 if relu else 0, native.stream_handle()), "ovc_linear")
@@ -68,18 +78,23 @@ def layer_norm(x, gamma, beta, *, residual=None, add=None, zero_rows=None, eps=1
     d = x.shape[-1]
     rows = x.numel() // d
     residual = None if residual is None else _dev(residual, "residual")
+    if residual is not None:
+        _expect(residual, x.shape, "residual")
+    gamma, beta = _dev(gamma.detach(), "gamma"), _dev(beta.detach(), "beta")
+    _expect(gamma, (d,), "gamma")
+    _expect(beta, (d,), "beta")
     add_rows = 0
     if add is not None:
         add = _dev(add, "add")
         add_rows = add.numel() // d
-        if rows % add_rows:
+        if add.shape[-1] != d or add_rows == 0 or rows % add_rows:
             raise native.OvcError("add rows {} do not divide rows {}".format(add_rows, rows))
     if zero_rows is not None:
         zero_rows = _as_u8(zero_rows, "zero_rows")
         if zero_rows.numel() != rows:
             raise native.OvcError("zero_rows has {} entries for {} rows".format(zero_rows.numel(), rows))
     y = torch.empty_like(x)
-    check(lib.ovc_layer_norm(_ptr(x), _ptr(residual), _ptr(_dev(gamma.detach(), "gamma")), _ptr(_dev(beta.detach(), "beta")),
+    check(lib.ovc_layer_norm(_ptr(x), _ptr(residual), _ptr(gamma), _ptr(beta),
                              _ptr(add), add_rows, _ptr(zero_rows), float(eps), _ptr(y), rows, d,
                              native.stream_handle()), "ovc_layer_norm")
     return y
@@ -96,6 +111,9 @@ def attention(q, k, v, heads: int, *, mask=None, geometry=None,
     q, k, v = _dev(q, "q"), _dev(k, "k"), _dev(v, "v")
     b, nq, hdk = q.shape
     nk = k.shape[1]
+    _expect(k, (b, nk, hdk), "k")
+    if v.dim() != 3 or v.shape[:2] != (b, nk) or hdk % heads or v.shape[2] % heads:
+        raise native.OvcError("v must be ({}, {}, heads*d_v) and q/k widths multiples of heads={}; got {}".format(b, nk, heads, tuple(v.shape)))
     dk, dv = hdk // heads, v.shape[2] // heads
     mask_sb = mask_sq = 0
     if mask is not None:
@@ -116,6 +134,8 @@ def attention(q, k, v, heads: int, *, mask=None, geometry=None,
         m_k, m_v, sk, sv = memory
         m_k, m_v = _dev(m_k.detach(), "m_k"), _dev(m_v.detach(), "m_v")
         m = m_k.shape[-2]
+        _expect(m_k.reshape(m, -1), (m, hdk), "m_k")
+        _expect(m_v.reshape(m, -1), (m, heads * dv), "m_v")
     out = torch.empty(b, nq, heads * dv, dtype=torch.float32, device=q.device)
     check(lib.ovc_attention(_ptr(q), _ptr(k), _ptr(v), b, nq, nk, heads, dk, dv, _ptr(mask), mask_sb, mask_sq,
                             _ptr(geometry), _ptr(m_k), _ptr(m_v), m, float(sk), float(sv), _ptr(out),
@@ -139,6 +159,7 @@ def region_position_encoding(batch: int, n: int, d: int, temperature: float = 10
     lib = native.load()
     if mask is not None:
         mask = _as_u8(mask, "mask")
+        _expect(mask, (batch, n), "mask")
         device = mask.device
     pe = torch.empty(batch, n, d, dtype=torch.float32, device=device)
     if not pe.is_cuda:
@@ -159,6 +180,7 @@ def embed(tokens, table, positions=None, position_table=None):
         positions = _dev(positions.expand_as(tokens), "positions", torch.int64)
         position_table = _dev(position_table.detach(), "position_table")
         pos_rows = position_table.shape[0]
+        _expect(position_table, (pos_rows, d), "position_table")
     y = torch.empty(*tokens.shape, d, dtype=torch.float32, device=tokens.device)
     check(lib.ovc_embed(_ptr(tokens), _ptr(positions), _ptr(table), table.shape[0], _ptr(position_table), pos_rows, _ptr(y),
                         tokens.numel(), d, native.stream_handle()), "ovc_embed")
@@ -168,6 +190,7 @@ def embed(tokens, table, positions=None, position_table=None):
 def sigmoid_gate(a, g):
     lib = native.load()
     a, g = _dev(a, "a"), _dev(g, "g")
+    _expect(g, a.shape, "g")
     y = torch.empty_like(a)
     check(lib.ovc_sigmoid_gate(_ptr(a), _ptr(g), _ptr(y), a.numel(), native.stream_handle()), "ovc_sigmoid_gate")
     return y
@@ -177,6 +200,9 @@ def gated_accumulate(acc, alpha, x, divisor: float = 1.0):
     lib = native.load()
     alpha, x = _dev(alpha, "alpha"), _dev(x, "x")
     acc = None if acc is None else _dev(acc, "acc")
+    _expect(alpha, x.shape, "alpha")
+    if acc is not None:
+        _expect(acc, x.shape, "acc")
     out = torch.empty_like(x)
     check(lib.ovc_gated_accumulate(_ptr(acc), _ptr(alpha), _ptr(x), float(divisor), _ptr(out), x.numel(),
                                    native.stream_handle()), "ovc_gated_accumulate")
@@ -198,7 +224,9 @@ def box_relation_weights(boxes, fc_weight, fc_bias, trignometric: bool):
     boxes = _dev(boxes, "boxes")
     fc_weight, fc_bias = _dev(fc_weight.detach(), "fc_weight"), _dev(fc_bias.detach(), "fc_bias")
     b, n = boxes.shape[:2]
+    _expect(boxes, (b, n, 4), "boxes")
     h, d_g = fc_weight.shape
+    _expect(fc_bias, (h,), "fc_bias")
     w = torch.empty(b, h, n, n, dtype=torch.float32, device=boxes.device)
     check(lib.ovc_box_relation_weights(_ptr(boxes), b, n, _ptr(fc_weight), _ptr(fc_bias), h, d_g,
                                        1 if trignometric else 0, _ptr(w), native.stream_handle()),
@@ -220,6 +248,8 @@ def beam_select(logp, running, alive, prev_words, eos_idx: int, k: int):
         alive = alive * (prev_words != eos_idx).to(alive.dtype).unsqueeze(-1)
     alive_c = _dev(alive.reshape(B, width), "alive")
     running_c = _dev(running.reshape(B, -1).expand(B, width), "running")
+    if not 1 <= k <= min(native.OVC_MAX_BEAM, width * V):
+        raise native.OvcError("beam size {} outside 1..{}".format(k, min(native.OVC_MAX_BEAM, width * V)))
     chosen = torch.empty(B, k, dtype=torch.int64, device=logp.device)
     score = torch.empty(B, k, dtype=torch.float32, device=logp.device)
     masked = torch.empty_like(logp)

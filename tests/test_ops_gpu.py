@@ -418,3 +418,31 @@ def test_embed_clamps_indices_instead_of_reading_out_of_bounds():
     got = ops.embed(tokens.to(DEV), table.to(DEV), positions.to(DEV), pos.to(DEV)).cpu()
     want = table[tokens.clamp(0, 9)] + pos[positions.clamp(0, 3)]
     np.testing.assert_array_equal(got.numpy(), want.numpy())
+
+
+def test_operator_wrappers_reject_mismatched_shapes():
+    """The kernels index with the caller's sizes; a tensor of another shape must raise on the host, not read
+    device memory out of bounds."""
+    from openviic_amd import native, ops
+    t = lambda *shape: torch.randn(*shape, device=DEV)
+    with pytest.raises(native.OvcError):
+        ops.linear(t(6, 32), t(16, 32), t(15))                               # bias length
+    with pytest.raises(native.OvcError):
+        ops.linear(t(6, 32), t(16, 32), residual=t(5, 16))                   # residual rows
+    with pytest.raises(native.OvcError):
+        ops.linear(t(6, 32), t(16, 40), x2=t(5, 8))                          # second input block rows
+    with pytest.raises(native.OvcError):
+        ops.layer_norm(t(4, 32), t(31), t(32))                               # gamma length
+    with pytest.raises(native.OvcError):
+        ops.layer_norm(t(4, 32), t(32), t(32), residual=t(3, 32))            # residual shape
+    with pytest.raises(native.OvcError):
+        ops.attention(t(2, 5, 32), t(2, 7, 32), t(2, 6, 32), 4)              # k / v disagree on the key count
+    with pytest.raises(native.OvcError):
+        ops.attention(t(2, 5, 32), t(2, 7, 32), t(2, 7, 32), 4, geometry=t(2, 4, 5, 6))
+    with pytest.raises(native.OvcError):
+        ops.sigmoid_gate(t(8, 16), t(8, 12))
+    with pytest.raises(native.OvcError):
+        ops.box_relation_weights(t(2, 5, 3), t(4, 4), t(4), False)           # boxes need 4 coordinates
+    with pytest.raises(native.OvcError):
+        ops.beam_select(t(2, 3, 50), t(2, 3), torch.ones(2, 3, 1, device=DEV), None, 2, 9)   # beam wider than the ABI's maximum
+    assert ops.linear(t(6, 32), t(16, 32), t(16)).shape == (6, 16)          # the well-formed call still works
