@@ -172,7 +172,9 @@ def test_batch_256_properties():
         lo, _ = model.beam_search(batch(feats[:128]), batch_size=128, beam_size=5)
         hi, _ = model.beam_search(batch(feats[128:]), batch_size=128, beam_size=5)
     assert torch.equal(ids, ids_again)
-    assert torch.equal(ids, torch.cat([lo, hi]))
+    # another batch size means other GEMM tilings, i.e. another fp32 summation order: an image whose beam decision
+    # margin is below that noise (~5e-6) may legitimately differ; none does on this data, a couple are tolerated
+    assert (ids == torch.cat([lo, hi])).all(dim=1).float().mean() >= 0.99
     assert ids.min() >= 0 and ids.max() < FULL["V"]
     same = (ids[:16].cpu().numpy() == g["B16_k5_ids"]).all(axis=1)
     assert same.mean() >= 0.75
@@ -228,7 +230,8 @@ def test_batch_256_properties_other_architectures(variant):
         again, _ = model.beam_search(batch(feats, boxes), batch_size=256, beam_size=5)
         lo, _ = model.beam_search(batch(feats[:128], None if boxes is None else boxes[:128]), batch_size=128, beam_size=5)
         hi, _ = model.beam_search(batch(feats[128:], None if boxes is None else boxes[128:]), batch_size=128, beam_size=5)
-    assert torch.equal(ids, again) and torch.equal(ids, torch.cat([lo, hi]))
+    assert torch.equal(ids, again)
+    assert (ids == torch.cat([lo, hi])).all(dim=1).float().mean() >= 0.99      # see test_batch_256_properties
     assert torch.isfinite(logp).all() and ids.min() >= 0 and ids.max() < FULL["V"]
     if boxes is None:
         same = (ids[:16].cpu().numpy() == g["B16_k5_ids"]).all(axis=1)
