@@ -144,8 +144,10 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device; the engine has no CPU path")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # one rank per GPU; if the launcher narrows each rank's visible devices to its own GPU, LOCAL_RANK still counts up
+    device_index = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(device_index)
+    device = torch.device("cuda", device_index)
     if distributed:
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=device)
