@@ -9,7 +9,9 @@
  * token ids are int64.  Nothing allocates, nothing synchronises, every launch goes to the
  * caller's hipStream_t; the return value is 0 on success or a negative OVC_E* code, and no
  * exception crosses the boundary.  Process-wide state is limited to caches and opt-in tools:
- * the GEMM tuning table, the hipGraph cache and the profiling counters.
+ * the GEMM tuning table, the hipGraph cache and the profiling counters, each behind its own
+ * mutex: the library may be driven from several host threads (one stream per thread; the debug
+ * hook ovc_debug_force_gemm_tiling is the one exception and says so).
  */
 #ifndef OVC_H_
 #define OVC_H_
@@ -170,8 +172,9 @@ typedef struct {
  * reference itself has no such limits, these are the template instances built so far:
  *   regions N <= 128;  beam k <= OVC_MAX_BEAM (8);  max_len <= 64;  any vocabulary (above 16384 words the
  *   selection streams each row k + 2 times instead of holding it in registers);
- *   d_model <= 2048 (multiple of 4);  d_k, d_v <= 64 (multiples of 4), heads*d_k == heads*d_v, a multiple
- *   of 64 and <= 1024;  layers <= OVC_MAX_LAYERS (8);  meshed levels <= OVC_MAX_LEVELS (4).
+ *   d_model <= 2048 (multiple of 4);  d_k == d_v in {4, 8, 16, 32, 64}, heads <= 32, heads*d_k a multiple
+ *   of 64 and <= 1024;  layers <= OVC_MAX_LAYERS (8);  meshed levels <= OVC_MAX_LEVELS (4) and equal to the
+ *   number of encoder layers (the multilevel encoder emits one level per layer).
  * tests/test_engine_gpu.py::test_unusual_dimensions_against_oracle runs each limit against the CPU oracle.
  *
  * Bytes of scratch the engine needs for batch B, N regions, beam k (return_probs adds the
@@ -219,14 +222,24 @@ int ovc_profile_read(int kind, int index, int64_t* launches, double* total_ms, d
 double ovc_profile_overhead_ms(void);
 const char* ovc_profile_kernel_name(int tiling);   /* "" past the last tiling */
 
-/* Measure every GEMM tiling on the shape y[M, nseg*seg_n] = x[M,K] W^T (nseg weight segments of
- * seg_n rows) and remember the fastest for this process; later ovc_linear / engine GEMMs of that
- * shape use it.  scratch: >= 4*(M*K + nseg*seg_n*K + M*nseg*seg_n) + 64 bytes of device memory
- * (contents are used as operands).  For single-segment shapes with few output tiles the 2- and 4-way
- * K splits (partial products summed by the consuming LayerNorm, engine only) are measured as well when
- * the scratch has room for 2x / 4x the output.  SYNCHRONISES the stream -- set-up time only. */
-int ovc_gemm_tune(int M, int seg_n, int nseg, int K, void* scratch, size_t scratch_bytes,
+/* GEMM K-order classes.  fp32 addition is not associative and beam search decides on fp32 comparisons, so the
+ * order in which a product sums over K is part of its definition here, never a tuning outcome:
+ *   kchains = 1   one fmaf chain over k (ovc_linear; the engine's M = B*N encoder-side products);
+ *   kchains = 4   four interleaved chains summed in chain order (the engine's M = B*beam decode-step products);
+ *   ksplit  = s   K cut into s contiguous slices whose raw partial products the consuming LayerNorm sums in
+ *                 slice order (engine only; a fixed function of K).
+ * All tilings of one class produce bit-identical results, so token ids do not depend on the batch size, on the
+ * GPU box or on what a timing run picked (the reference is deterministic on CPU: torch.sort path,
+ * models/modules/beam_search.py:36-39).
+ *
+ * ovc_gemm_tune measures every tiling OF THE GIVEN CLASS on the shape y[M, nseg*seg_n] = x[M,K] W^T (nseg weight
+ * segments of seg_n rows; ksplit > 1 needs nseg == 1) and remembers the fastest for this process; later GEMMs of
+ * that shape and class use it, and shapes whose M is within a factor of two of a measured one borrow its entry.
+ * scratch: >= 4*(M*K + nseg*seg_n*K + ksplit*M*nseg*seg_n) + 64 bytes of device memory (contents are used as
+ * operands).  SYNCHRONISES the stream -- set-up time only.  Thread-safe. */
+int ovc_gemm_tune(int M, int seg_n, int nseg, int K, int kchains, int ksplit, void* scratch, size_t scratch_bytes,
                   ovc_stream stream);
+long ovc_gemm_tune_calls(void);        /* measurements run so far in this process */
 
 /* What ovc_gemm_tune minimises: the time of `copies` identical products co-running in one launch (1..8).
  * 1 (default) ranks tilings by isolated latency, which favours many small tiles; with several independent
@@ -234,14 +247,29 @@ int ovc_gemm_tune(int M, int seg_n, int nseg, int K, void* scratch, size_t scrat
  * because they spend fewer CU-seconds and less L2 traffic per FLOP.  Affects later ovc_gemm_tune calls. */
 int ovc_gemm_tune_objective(int copies);
 
-/* Read / preset the remembered choice of a shape (-1 = not tuned): lets a host persist tuning results.
- * The value is  tiling | split << 8 | split_tiling << 16  (split 1: no K split, split_tiling 0). */
-int ovc_gemm_tuned_get(int M, int seg_n, int nseg, int K);
-int ovc_gemm_tuned_set(int M, int seg_n, int nseg, int K, int code);
+/* Read / preset the remembered tiling of (shape, class): lets a host persist tuning results.  get returns the
+ * tiling index or -1; near != 0 also accepts the entry of the same product with the closest M within a factor of
+ * two (what a launch falls back to).  set refuses a tiling of another class. */
+int ovc_gemm_tuned_get(int M, int seg_n, int nseg, int K, int kchains, int ksplit, int near);
+int ovc_gemm_tuned_set(int M, int seg_n, int nseg, int K, int kchains, int ksplit, int tiling);
 
-/* Tuning hook (tools/gemm_bench.py): force GEMM tiling 0..6 (see csrc/gemm.hip) for every
- * following ovc_linear / engine GEMM in this process; -1 restores the automatic choice. */
+/* The distinct GEMMs the engine issues for batch B, N regions, beam k: up to `capacity` records of six int32
+ * (M, seg_n, nseg, K, kchains, ksplit) are written to `shapes`; returns the number of distinct shapes (which may
+ * exceed capacity) or a negative OVC_E* code.  Host only: no launch, no device access. */
+int ovc_engine_gemm_shapes(const ovc_model* m, int B, int N, int k, int32_t* shapes, int capacity);
+
+/* hipGraph cache housekeeping: entries are evicted least-recently-used beyond OVC_GRAPH_CACHE_MAX (default 24);
+ * a host that frees or replaces a workspace must drop that workspace's graphs first. */
+int ovc_graph_cache_drop_workspace(const void* workspace);   /* returns the number of entries dropped */
+int ovc_graph_cache_size(void);
+
+/* Debug / measurement hooks (tools/, tests/).  ovc_debug_force_gemm_tiling: every following GEMM of the forced
+ * tiling's class uses it (-1 restores the automatic choice); process-wide, not for use while other threads decode.
+ * ovc_debug_linear_tiling: y = x W^T + bias by ONE named tiling (its class follows from the tiling; the name is
+ * ovc_profile_kernel_name(tiling)); with ksplit > 1, y receives the ksplit raw partial products [ksplit][M][N]. */
 int ovc_debug_force_gemm_tiling(int tiling);
+int ovc_debug_linear_tiling(const float* x, int K, const float* W, const float* bias, float* y, int M, int N,
+                            int tiling, int ksplit, ovc_stream stream);
 /* `iters` back-to-back launches of y = x W^T + bias (x [M,K], W [N,K]) with no host work between. */
 int ovc_debug_repeat_linear(const float* x, int K, const float* W, const float* bias, float* y,
                             int M, int N, int iters, ovc_stream stream);

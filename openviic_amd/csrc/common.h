@@ -53,18 +53,24 @@ struct GemmArgs {
     int ksplit;          // > 1: K is cut into ksplit equal slices, slice s writes its raw partial product (no bias /
                          // activation / residual) to seg[0].C + s * part_stride; the consumer sums the slices in order
     long part_stride;    // floats between two partial outputs
+    int kchains;         // K-order class (gemm.hip): 1 (or 0) = one summation chain over k, 4 = four interleaved chains
+                         // summed in chain order.  Part of the product's DEFINITION: every tiling of a class gives the
+                         // same bits, so the caller fixes it per call site and no timing can change a result.
     GemmSegment seg[OVC_MAX_SEGMENTS];
 };
 
+// Per-launch options (never global state: several host threads may drive the library at once).
+struct GemmLaunchOpts {
+    int forced_tiling = -1;                 // >= 0: use exactly this tiling (must fit the problem and its class)
+    int copies = 1;                         // tuner: gridDim.z identical copies co-running in one launch
+    hipEvent_t start = nullptr, stop = nullptr;   // kernel-scoped events (dispatch begin / end timestamps) for profiling
+};
+
 // Launches C = act([A1|A2] W^T + bias) + R on `stream`; returns an OVC_* code.
-int ovc_gemm_launch(const GemmArgs& args, hipStream_t stream);
-// Same launch with kernel-scoped events (dispatch begin / end timestamps) for profiling.
-int ovc_gemm_launch_timed(const GemmArgs& args, hipStream_t stream, hipEvent_t start, hipEvent_t stop);
-int ovc_gemm_pick_tiling(const GemmArgs& args);      // index of the tiling ovc_gemm_launch will use
-// K split the tuner measured as fastest for a single-segment M x N x K product whose consumer can sum partial
-// outputs (1 = none; also for shapes that were never tuned).  At most kMaxKSplit.
+int ovc_gemm_launch(const GemmArgs& args, hipStream_t stream, const GemmLaunchOpts& opts = GemmLaunchOpts{});
+int ovc_gemm_pick_tiling(const GemmArgs& args, const GemmLaunchOpts& opts = GemmLaunchOpts{});   // tiling ovc_gemm_launch will use
+int ovc_gemm_tiling_class(int tiling);               // chains of a tiling's K-order class (0 = no such tiling)
 constexpr int kMaxKSplit = 4;
-int ovc_gemm_split_for(int M, int N, int K);
 // LayerNorm(sum_s parts[s] + bias + residual), nparts in {2, 4}, bias and residual required: the consumer side of
 // a K-split GEMM (rowops.hip).
 int ovc_layer_norm_parts(const float* parts, int nparts, long part_stride, const float* bias, const float* residual,

@@ -12,7 +12,11 @@
 //   * beam re-ordering is an ancestor-slot table (int32 [rows, T]) read by the self-attention
 //     kernel; the reference physically gathers every cache (beam_search.py:19-34).
 #include <algorithm>
+#include <array>
+#include <cstdlib>
+#include <list>
 #include <map>
+#include <atomic>
 #include <mutex>
 #include <tuple>
 #include <vector>
@@ -26,6 +30,11 @@ namespace {
         const int _rc = (expr);            \
         if (_rc != OVC_OK) return _rc;     \
     } while (0)
+// a launch that is skipped while the engine only enumerates its GEMM shapes (Engine::dry)
+#define RUN(expr)                          \
+    do {                                   \
+        if (!e.dry) TRY(expr);             \
+    } while (0)
 
 // ---------------------------------------------------------------------------------------------
 // opt-in GEMM timing (bench.py roofline leg)
@@ -33,13 +42,14 @@ namespace {
 struct ProfileRecord { hipEvent_t start, stop; double flops; int cls, tiling; };
 struct ProfileBin { int64_t launches; double ms, flops; };
 constexpr int kProfileTilings = 16;
-bool g_profile_on = false;
+std::atomic<bool> g_profile_on{false};
+std::mutex g_profile_mutex;                      // guards everything below (several host threads may decode at once)
 std::vector<ProfileRecord> g_profile;            // open records (events not yet resolved)
 std::vector<ProfileRecord> g_profile_empty;      // back-to-back event pairs: the bracket's own overhead
 ProfileBin g_by_class[OVC_PROFILE_CLASSES], g_by_tiling[kProfileTilings];
 double g_profile_overhead_ms = 0.0;
 
-void profile_resolve() {
+void profile_resolve() {               // caller holds g_profile_mutex
     if (g_profile.empty() && g_profile_empty.empty()) return;
     std::vector<float> empties;
     for (ProfileRecord& r : g_profile_empty) {
@@ -107,14 +117,21 @@ bool model_ok(const ovc_model* m) {
     if (m->n_enc < 1 || m->n_enc > OVC_MAX_LAYERS || m->n_dec < 1 || m->n_dec > OVC_MAX_LAYERS) return false;
     if (m->n_levels < 1 || m->n_levels > OVC_MAX_LEVELS) return false;
     if (m->d_model <= 0 || (m->d_model & 3) || m->d_model > 2048) return false;
-    if (m->d_k <= 0 || m->d_k > 64 || (m->d_k & 3) || m->d_v <= 0 || m->d_v > 64 || (m->d_v & 3)) return false;
-    if ((m->d_feat & 3) || (m->d_ff & 3) || m->heads <= 0 || m->vocab <= 1) return false;
+    // head size: the decode attention kernels need d_k == d_v in {4, 8, 16, 32, 64} (attention.hip: the self-attention
+    // reduces a head inside a power-of-two lane group), at most 32 heads and heads * d_k <= 1024
+    if (m->d_k != m->d_v || m->d_k < 4 || m->d_k > 64 || (m->d_k & (m->d_k - 1))) return false;
+    if ((m->d_feat & 3) || (m->d_ff & 3) || m->heads <= 0 || m->heads > 32 || m->heads * m->d_k > 1024 || m->vocab <= 1) return false;
+    if (m->d_feat <= 0 || m->d_ff <= 0 || m->memory < 0) return false;
     if (m->max_len < 1 || m->max_len > 64) return false;
     if (m->bos_idx < 0 || m->bos_idx >= m->vocab || m->pad_idx < 0 || m->pad_idx >= m->vocab || m->eos_idx < 0 || m->eos_idx >= m->vocab) return false;
     // fused q|k|v and cross k|v GEMMs need segment widths that are multiples of the 64-wide tile
     if ((m->heads * m->d_k) % 64 || (m->heads * m->d_v) % 64 || (m->heads * m->d_k) != (m->heads * m->d_v)) return false;
     if (m->dec_kind == OVC_DEC_MESHED && m->enc_kind != OVC_ENC_MULTILEVEL) return false;
     if (m->dec_kind != OVC_DEC_MESHED && m->n_levels != 1) return false;
+    // the multilevel encoder writes one level per layer (engine.hip run_encoder_layers): the meshed decoder must
+    // consume exactly that many
+    if (m->enc_kind == OVC_ENC_MULTILEVEL && m->n_levels != m->n_enc) return false;
+    if (m->enc_kind != OVC_ENC_MULTILEVEL && m->n_levels != 1) return false;
     return true;
 }
 
@@ -197,13 +214,38 @@ __global__ void interleave_levels_kernel(const float* __restrict__ levels, float
 // ---------------------------------------------------------------------------------------------
 // launch helpers
 // ---------------------------------------------------------------------------------------------
+// K slices of the M = B*k projections back to d_model whose consumer is the AddNorm LayerNorm (it sums the slices in
+// order and applies bias and residual).  Like GemmArgs::kchains this is part of the product's definition -- the slices
+// are summed in a fixed order -- so it is a pure function of K, never of a timing or of M: 2 slices below K = 1024,
+// 4 from there on (measured on 1280 x 512 x {512, 2048}: 12.3 -> 11.1 us and 37.3 -> 27.2 us).  OVC_KSPLIT_SMALL /
+// OVC_KSPLIT_LARGE override the two values for A/B measurements (they change the summation order, hence low-order bits).
+int decode_ksplit(int K) {
+    static const int small = [] { const char* e = getenv("OVC_KSPLIT_SMALL"); return e ? atoi(e) : 2; }();
+    static const int large = [] { const char* e = getenv("OVC_KSPLIT_LARGE"); return e ? atoi(e) : 4; }();
+    int s = K >= 1024 ? large : small;
+    if (s != 1 && s != 2 && s != 4) s = 1;
+    while (s > 1 && K % (s * 32)) s >>= 1;          // a slice is a whole number of 32-deep K tiles
+    return s;
+}
+
+using GemmShape = std::array<int, 6>;               // M, seg_n, nseg, K, kchains, ksplit
+
 struct Engine {
     const ovc_model* m;
     hipStream_t stream;
-    int gemm_class;
+    int gemm_class;                                  // profiling bin (OVC_PROFILE_CLASSES)
+    int kchains = 1;                                 // K-order class of the GEMMs issued next (set per call site group)
+    std::vector<GemmShape>* dry = nullptr;           // shape enumeration: record every GEMM, launch nothing
 
     int gemm(GemmArgs& a) {
-        if (!g_profile_on) return ovc_gemm_launch(a, stream);
+        a.kchains = kchains;
+        if (dry) {
+            const GemmShape sh{a.M, a.seg_n, a.nseg, a.K1 + a.K2, kchains, a.ksplit > 1 ? a.ksplit : 1};
+            if (std::find(dry->begin(), dry->end(), sh) == dry->end()) dry->push_back(sh);
+            return OVC_OK;
+        }
+        if (!g_profile_on.load()) return ovc_gemm_launch(a, stream);
+        std::lock_guard<std::mutex> lock(g_profile_mutex);
         if (g_profile.empty() && g_profile_empty.empty()) {
             // calibrate the bracket: event pairs with nothing in between
             for (int i = 0; i < 16; ++i) {
@@ -220,7 +262,9 @@ struct Engine {
         rec.cls = gemm_class;
         rec.tiling = ovc_gemm_pick_tiling(a);
         // kernel-scoped events: the dispatch's own begin / end timestamps (no marker latency in between)
-        const int rc = ovc_gemm_launch_timed(a, stream, rec.start, rec.stop);
+        GemmLaunchOpts opts{};
+        opts.start = rec.start; opts.stop = rec.stop;
+        const int rc = ovc_gemm_launch(a, stream, opts);
         g_profile.push_back(rec);
         return rc;
     }
@@ -234,15 +278,16 @@ struct Engine {
         return gemm(a);
     }
 
-    // out = LayerNorm(x W^T + b + residual), rows flagged in zero_rows cleared.  Shapes for which the tuner found a
-    // K split faster (the M = B*k projections back to d_model, K = d_ff above all) run the GEMM as `split` slices
-    // writing partial products; the LayerNorm kernel sums them in slice order and applies bias and residual.
+    // out = LayerNorm(x W^T + b + residual), rows flagged in zero_rows cleared.  With a partial-product buffer (the
+    // M = B*k decode-step projections back to d_model) the GEMM runs as decode_ksplit(K) slices writing raw partial
+    // products; the LayerNorm kernel sums them in slice order and applies bias and residual.
     int linear_ln(const float* x, int K, const ovc_lin& l, const float* residual, const ovc_norm& ln,
                   const uint8_t* zero_rows, float* y_tmp, float* part, float* out, int M) {
         const int d = m->d_model;
-        const int split = part && l.b && residual ? ovc_gemm_split_for(M, d, K) : 1;
+        const int split = part && l.b && residual ? decode_ksplit(K) : 1;
         if (split != 2 && split != 4) {
             TRY(linear(x, K, l, residual, y_tmp, M, d, 0));
+            if (dry) return OVC_OK;
             return ovc_layer_norm(y_tmp, nullptr, ln.g, ln.b, nullptr, 0, zero_rows, m->ln_eps, out, M, d, stream);
         }
         GemmArgs a{};
@@ -250,6 +295,7 @@ struct Engine {
         a.ksplit = split; a.part_stride = (long)M * d;
         a.seg[0] = GemmSegment{l.w, nullptr, part};
         TRY(gemm(a));
+        if (dry) return OVC_OK;
         return ovc_layer_norm_parts(part, split, a.part_stride, l.b, residual, ln.g, ln.b, zero_rows, m->ln_eps, out, M, d, stream);
     }
 
@@ -270,6 +316,7 @@ struct Engine {
         } else {
             TRY(gemm(a));
         }
+        if (dry) return OVC_OK;
         return ovc_sigmoid_gate(info, gate, x, (long)M * d, stream);
     }
 
@@ -285,12 +332,13 @@ int run_encoder_inputs(Engine& e, Workspace& w, const float* features, const flo
     const ovc_model* m = e.m;
     const int BN = B * N, d = m->d_model;
     hipStream_t s = e.stream;
-    if (m->enc_kind == OVC_ENC_GEOMETRIC && (!boxes || !m->fc_g_w || !m->fc_g_b)) return OVC_EINVAL;
+    if (!e.dry && m->enc_kind == OVC_ENC_GEOMETRIC && (!boxes || !m->fc_g_w || !m->fc_g_b)) return OVC_EINVAL;
     e.gemm_class = 0;
-    TRY(ovc_zero_row_mask(features, BN, m->d_feat, w.enc_mask, s));
+    e.kchains = 1;            // M = B*N products: one summation chain (gemm.hip, K-order classes)
+    RUN(ovc_zero_row_mask(features, BN, m->d_feat, w.enc_mask, s));
     TRY(e.linear(features, m->d_feat, m->proj, nullptr, w.ey, BN, d, 0));
     if (m->enc_kind == OVC_ENC_GEOMETRIC)
-        TRY(ovc_box_relation_weights(boxes, B, N, m->fc_g_w, m->fc_g_b, m->heads, m->d_g, m->trig, w.geometry, s));
+        RUN(ovc_box_relation_weights(boxes, B, N, m->fc_g_w, m->fc_g_b, m->heads, m->d_g, m->trig, w.geometry, s));
     return OVC_OK;
 }
 
@@ -299,8 +347,9 @@ int run_encoder_layers(Engine& e, Workspace& w, int B, int N) {
     const int BN = B * N, d = m->d_model, hk = m->heads * m->d_k, hv = m->heads * m->d_v;
     hipStream_t s = e.stream;
     e.gemm_class = 1;
-    TRY(ovc_region_position_encoding(nullptr, 1, N, d, 10000.0f, 0, 0.f, w.pe, s));
-    TRY(ovc_layer_norm(w.ey, nullptr, m->enc_ln.g, m->enc_ln.b, w.pe, N, nullptr, m->ln_eps, w.xe[0], BN, d, s));
+    e.kchains = 1;
+    RUN(ovc_region_position_encoding(nullptr, 1, N, d, 10000.0f, 0, 0.f, w.pe, s));
+    RUN(ovc_layer_norm(w.ey, nullptr, m->enc_ln.g, m->enc_ln.b, w.pe, N, nullptr, m->ln_eps, w.xe[0], BN, d, s));
 
     float* x = w.xe[0];
     float* x1 = w.xe[1];
@@ -313,11 +362,11 @@ int run_encoder_layers(Engine& e, Workspace& w, int B, int N) {
         a.seg[2] = GemmSegment{at.v.w, at.v.b, w.ev};
         TRY(e.gemm(a));
         const int mem = at.m_k ? m->memory : 0;
-        TRY(ovc_attention(w.eq, w.ek, w.ev, B, N, N, m->heads, m->d_k, m->d_v, w.enc_mask, N, 0,
+        RUN(ovc_attention(w.eq, w.ek, w.ev, B, N, N, m->heads, m->d_k, m->d_v, w.enc_mask, N, 0,
                           m->enc_kind == OVC_ENC_GEOMETRIC ? w.geometry : nullptr, at.m_k, at.m_v, mem,
                           sqrtf((float)m->d_k), sqrtf((float)(mem > 0 ? mem : 1)), w.eatt, s));
         TRY(e.linear(w.eatt, hv, at.o, x, w.ey, BN, d, 0));
-        TRY(ovc_layer_norm(w.ey, nullptr, at.ln.g, at.ln.b, nullptr, 0, nullptr, m->ln_eps, x1, BN, d, s));
+        RUN(ovc_layer_norm(w.ey, nullptr, at.ln.g, at.ln.b, nullptr, 0, nullptr, m->ln_eps, x1, BN, d, s));
         TRY(e.aoa(at, x, x1, w.einfo, w.egate, BN));
         // layer output: straight into the level slot (multilevel) or the ping-pong buffer
         float* out = m->enc_kind == OVC_ENC_MULTILEVEL ? w.enc_levels + (size_t)l * BN * d
@@ -339,6 +388,7 @@ int project_cross_kv(Engine& e, Workspace& w, int B, int N) {
     const ovc_model* m = e.m;
     const int BN = B * N, d = m->d_model, hk = m->heads * m->d_k, lv = m->n_levels, L = m->n_dec;
     e.gemm_class = 1;
+    e.kchains = 1;
     for (int lvl = 0; lvl < lv; ++lvl) {
         for (int l0 = 0; l0 < L; l0 += OVC_MAX_SEGMENTS / 2) {
             GemmArgs a{};
@@ -365,13 +415,14 @@ int run_decode_step(Engine& e, Workspace& w, int B, int N, int k, int t, int ret
     const int cur = t & 1, nxt = cur ^ 1;
     uint8_t* padflag_t = w.padflag + (size_t)t * R;
 
-    if (t == 0) {       // later steps: the previous step's update kernel has written the input rows and pad flags
+    if (t == 0 && !e.dry) {       // later steps: the previous step's update kernel has written the input rows and pad flags
         hipLaunchKernelGGL(decode_embed_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, w.tok, m->bos_idx, m->pad_idx, t,
                            m->word_emb, m->pos_emb, w.x, padflag_t, rows, d);
         OVC_RETURN_IF_LAUNCH_FAILED();
     }
 
     e.gemm_class = 2;
+    e.kchains = 4;            // M = B*width products: four chains, so that 32x32 / 32x64 tiles can spread them over waves
     float* x = w.x;
     for (int l = 0; l < m->n_dec; ++l) {
         const ovc_dec_layer& dl = m->dec[l];
@@ -388,7 +439,7 @@ int run_decode_step(Engine& e, Workspace& w, int B, int N, int k, int t, int ret
         sa.q = w.q; sa.ldq = hk; sa.kcache = kc; sa.vcache = vc; sa.pos_stride = (size_t)R * hk; sa.ldkv = hk;
         sa.anc = w.anc[cur]; sa.anc_ld = T; sa.padflag = w.padflag; sa.pad_ld = R; sa.t = t;
         sa.h = m->heads; sa.dk = m->d_k; sa.dv = m->d_v; sa.out = w.att; sa.ldo = hv;
-        TRY(ovc_decode_self_attention(sa, rows, s));
+        RUN(ovc_decode_self_attention(sa, rows, s));
         TRY(e.linear_ln(w.att, hv, dl.self_att.o, x, dl.self_att.ln, nullptr, w.y, w.part, w.x1, rows));
         TRY(e.aoa(dl.self_att, x, w.x1, w.info, w.gate, rows));
 
@@ -399,7 +450,7 @@ int run_decode_step(Engine& e, Workspace& w, int B, int N, int k, int t, int ret
         ca.kx = w.kx + (size_t)l * lv * B * N * hk; ca.vx = w.vx + (size_t)l * lv * B * N * hv;
         ca.level_stride = (size_t)B * N * hk; ca.ldkv = hk; ca.encmask = w.enc_mask; ca.n = N; ca.width = width;
         ca.heads = m->heads; ca.dk = m->d_k; ca.dv = m->d_v; ca.out = w.att; ca.out_level_stride = (size_t)rows * hv; ca.ldo = hv;
-        TRY(ovc_decode_cross_attention(ca, B, m->heads, lv, s));
+        RUN(ovc_decode_cross_attention(ca, B, m->heads, lv, s));
         float* ffn_in;
         if (m->dec_kind == OVC_DEC_MESHED) {
             // decoders.py:51-73: one shared enc_attn per level, sigmoid-gated sum / sqrt(levels).  The levels'
@@ -412,12 +463,12 @@ int run_decode_step(Engine& e, Workspace& w, int B, int N, int k, int t, int ret
                 o.R = w.x1; o.ldr = d; o.res_mod = rows;
                 o.seg[0] = GemmSegment{dl.cross_att.o.w, dl.cross_att.o.b, w.ymesh};
                 TRY(e.gemm(o));
-                TRY(ovc_layer_norm(w.ymesh, nullptr, dl.cross_att.ln.g, dl.cross_att.ln.b, nullptr, 0, nullptr, m->ln_eps,
+                RUN(ovc_layer_norm(w.ymesh, nullptr, dl.cross_att.ln.g, dl.cross_att.ln.b, nullptr, 0, nullptr, m->ln_eps,
                                    w.enc_att, lv * rows, d, s));
             } else {
                 for (int lvl = 0; lvl < lv; ++lvl) {      // AoA gates need the per-level pair (x1, enc_att_l)
                     TRY(e.linear(w.att + (size_t)lvl * rows * hv, hv, dl.cross_att.o, w.x1, w.y, rows, d, 0));
-                    TRY(ovc_layer_norm(w.y, nullptr, dl.cross_att.ln.g, dl.cross_att.ln.b, nullptr, 0, nullptr, m->ln_eps,
+                    RUN(ovc_layer_norm(w.y, nullptr, dl.cross_att.ln.g, dl.cross_att.ln.b, nullptr, 0, nullptr, m->ln_eps,
                                        w.enc_att + lvl * nrd, rows, d, s));
                     TRY(e.aoa(dl.cross_att, w.x1, w.enc_att + lvl * nrd, w.info, w.gate, rows));
                 }
@@ -437,7 +488,7 @@ int run_decode_step(Engine& e, Workspace& w, int B, int N, int k, int t, int ret
                 }
                 if (fused) { g.nseg = lv; TRY(e.gemm(g)); }
             }
-            TRY(ovc_meshed_mix(w.alpha, w.enc_att, lv, (long)nrd, sqrtf((float)lv), w.mixed, s));
+            RUN(ovc_meshed_mix(w.alpha, w.enc_att, lv, (long)nrd, sqrtf((float)lv), w.mixed, s));
             ffn_in = w.mixed;
         } else {
             TRY(e.linear_ln(w.att, hv, dl.cross_att.o, w.x1, dl.cross_att.ln, nullptr, w.y, w.part, w.x2, rows));
@@ -463,7 +514,7 @@ int run_decode_step(Engine& e, Workspace& w, int B, int N, int k, int t, int ret
     bs.cand_v = w.cand_v; bs.cand_i = w.cand_i; bs.chosen = nullptr; bs.score = nullptr;   // merged by the update kernel
     bs.masked_logp = return_probs ? w.all_buf + (size_t)t * R * m->vocab : nullptr;
     bs.row_max_out = w.row_max; bs.row_lsum_out = w.row_lsum;
-    TRY(ovc_beam_select_launch(bs, B, s));
+    RUN(ovc_beam_select_launch(bs, B, s));
     BeamUpdateArgs bu{};
     bu.cand_v = w.cand_v; bu.cand_i = w.cand_i; bu.logits = w.logits; bu.ld = ldv;
     bu.row_max = w.row_max; bu.row_lsum = w.row_lsum;
@@ -475,12 +526,13 @@ int run_decode_step(Engine& e, Workspace& w, int B, int N, int k, int t, int ret
         bu.word_emb = m->word_emb; bu.pos_emb = m->pos_emb; bu.next_x = w.x; bu.next_padflag = w.padflag + (size_t)(t + 1) * R;
         bu.d_model = d; bu.pad = m->pad_idx;
     }
-    return ovc_beam_update_launch(bu, B, s);
+    RUN(ovc_beam_update_launch(bu, B, s));
+    return OVC_OK;
 }
 
 }  // namespace
 
-extern "C" int ovc_abi_version(void) { return 1; }
+extern "C" int ovc_abi_version(void) { return 2; }
 
 extern "C" const char* ovc_build_info(void) {
     return "libovc gfx950 (CDNA4) fp32: v_mfma_f32_32x32x2_f32 GEMM + attention, HIP " __DATE__;
@@ -489,6 +541,22 @@ extern "C" const char* ovc_build_info(void) {
 extern "C" size_t ovc_workspace_bytes(const ovc_model* m, int B, int N, int k, int return_probs) {
     if (!model_ok(m) || B <= 0 || N <= 0 || N > 128 || k <= 0 || k > OVC_MAX_BEAM) return 0;
     return carve(m, nullptr, B, N, k, return_probs).bytes;
+}
+
+// Every distinct GEMM the engine issues for (B, N, k), found by running the launch sequence itself in dry mode (no
+// launch, no device access: the workspace is carved at a fake base address that is never dereferenced).
+extern "C" int ovc_engine_gemm_shapes(const ovc_model* m, int B, int N, int k, int32_t* shapes, int capacity) {
+    if (!model_ok(m) || B <= 0 || N <= 0 || N > 128 || k <= 0 || k > OVC_MAX_BEAM || capacity < 0 || (capacity > 0 && !shapes)) return OVC_EINVAL;
+    Workspace w = carve(m, reinterpret_cast<void*>(uintptr_t(1) << 20), B, N, k, 0);
+    std::vector<GemmShape> found;
+    Engine e{m, nullptr, 0};
+    e.dry = &found;
+    TRY(run_encoder(e, w, nullptr, nullptr, B, N));
+    TRY(project_cross_kv(e, w, B, N));
+    for (int t = 0; t < (m->max_len < 2 ? m->max_len : 2); ++t) TRY(run_decode_step(e, w, B, N, k, t, 0));   // step 0: B rows, later steps: B*k
+    for (size_t i = 0; i < found.size() && (int)i < capacity; ++i)
+        for (int j = 0; j < 6; ++j) shapes[i * 6 + j] = found[i][j];
+    return (int)found.size();
 }
 
 extern "C" int ovc_encode(const ovc_model* m, const float* features, const float* boxes, int B, int N,
@@ -552,9 +620,38 @@ struct GraphKey {
         return std::tie(model_hash, ws, B, N, k, out_size) < std::tie(o.model_hash, o.ws, o.B, o.N, o.k, o.out_size);
     }
 };
-struct GraphEntry { int calls; bool unsupported; hipGraph_t graph; hipGraphExec_t exec; };
+struct GraphEntry { int calls; bool unsupported; hipGraph_t graph; hipGraphExec_t exec; hipStream_t last_stream; uint64_t last_use; };
 std::map<GraphKey, GraphEntry> g_graphs;
 std::mutex g_graph_mutex;
+uint64_t g_graph_tick = 0;
+
+// Captured graphs hold ~740 kernel nodes each; real-data batches bring a new (N bucket, batch size) now and then, so
+// the cache is bounded (OVC_GRAPH_CACHE_MAX entries, default 24) and evicts the least recently used entry.
+size_t graph_cache_capacity() {
+    static const size_t cap = [] { const char* e = getenv("OVC_GRAPH_CACHE_MAX"); const long v = e ? atol(e) : 24; return (size_t)(v < 1 ? 1 : v); }();
+    return cap;
+}
+
+void destroy_entry(GraphEntry& g) {       // caller holds g_graph_mutex
+    if (g.exec) {
+        if (g.last_stream) (void)hipStreamSynchronize(g.last_stream);   // a replay may still be running
+        (void)hipGraphExecDestroy(g.exec);
+    }
+    if (g.graph) (void)hipGraphDestroy(g.graph);
+    g.exec = nullptr; g.graph = nullptr;
+}
+
+void evict_lru(const GraphKey& keep) {     // caller holds g_graph_mutex
+    while (g_graphs.size() > graph_cache_capacity()) {
+        auto victim = g_graphs.end();
+        for (auto it = g_graphs.begin(); it != g_graphs.end(); ++it)
+            if (!(!(it->first < keep) && !(keep < it->first)) && (victim == g_graphs.end() || it->second.last_use < victim->second.last_use))
+                victim = it;
+        if (victim == g_graphs.end()) return;
+        destroy_entry(victim->second);
+        g_graphs.erase(victim);
+    }
+}
 
 uint64_t hash_bytes(const void* p, size_t n) {
     const unsigned char* b = static_cast<const unsigned char*>(p);
@@ -595,6 +692,9 @@ extern "C" int ovc_beam_search_graph(const ovc_model* m, const float* features, 
     std::lock_guard<std::mutex> lock(g_graph_mutex);
     GraphEntry& entry = g_graphs[key];
     entry.calls += 1;
+    entry.last_use = ++g_graph_tick;
+    entry.last_stream = e.stream;
+    evict_lru(key);
 
     TRY(run_encoder_inputs(e, w, features, boxes, B, N));
     // The legacy null stream cannot be captured (hipErrorStreamCaptureUnsupported): plain launches there.
@@ -627,15 +727,28 @@ extern "C" int ovc_beam_search_graph(const ovc_model* m, const float* features, 
 
 extern "C" int ovc_graph_cache_clear(void) {
     std::lock_guard<std::mutex> lock(g_graph_mutex);
-    for (auto& kv : g_graphs) {
-        if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
-        if (kv.second.graph) (void)hipGraphDestroy(kv.second.graph);
-    }
+    for (auto& kv : g_graphs) destroy_entry(kv.second);
     g_graphs.clear();
     return OVC_OK;
 }
 
+extern "C" int ovc_graph_cache_drop_workspace(const void* workspace) {
+    std::lock_guard<std::mutex> lock(g_graph_mutex);
+    int dropped = 0;
+    for (auto it = g_graphs.begin(); it != g_graphs.end();) {
+        if (it->first.ws == workspace) { destroy_entry(it->second); it = g_graphs.erase(it); ++dropped; }
+        else ++it;
+    }
+    return dropped;
+}
+
+extern "C" int ovc_graph_cache_size(void) {
+    std::lock_guard<std::mutex> lock(g_graph_mutex);
+    return (int)g_graphs.size();
+}
+
 extern "C" int ovc_profile_enable(int on) {
+    std::lock_guard<std::mutex> lock(g_profile_mutex);
     if (on && !g_profile_on) {
         profile_resolve();
         for (ProfileBin& b : g_by_class) b = ProfileBin{};
@@ -648,6 +761,7 @@ extern "C" int ovc_profile_enable(int on) {
 extern "C" int ovc_profile_read(int kind, int index, int64_t* launches, double* total_ms, double* total_flops) {
     if (!launches || !total_ms || !total_flops) return OVC_EINVAL;
     if (kind == 0 ? (index < 0 || index >= OVC_PROFILE_CLASSES) : (kind != 1 || index < 0 || index >= kProfileTilings)) return OVC_EINVAL;
+    std::lock_guard<std::mutex> lock(g_profile_mutex);
     profile_resolve();
     const ProfileBin& b = kind == 0 ? g_by_class[index] : g_by_tiling[index];
     *launches = b.launches; *total_ms = b.ms; *total_flops = b.flops;
@@ -655,6 +769,7 @@ extern "C" int ovc_profile_read(int kind, int index, int64_t* launches, double* 
 }
 
 extern "C" double ovc_profile_overhead_ms(void) {
+    std::lock_guard<std::mutex> lock(g_profile_mutex);
     profile_resolve();
     return g_profile_overhead_ms;
 }

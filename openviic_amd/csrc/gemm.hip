@@ -25,8 +25,21 @@
 //   * K split across workgroups (gridDim.y slices writing raw partial products that the consuming
 //     LayerNorm sums in order) for the M = B*k products back to d_model, whose 32x32 tiles are bound by
 //     the CU's L2 port rather than by the matrix cores.
-//   * Twelve tilings (128x128 ... 32x32 with a 4-way K split inside the workgroup; K tile 32 or 64);
-//     ovc_gemm_tune measures them per shape, a cost model covers shapes that were never measured.
+//   * K-order classes (GemmArgs::kchains).  fp32 addition is not associative, and beam search takes
+//     decisions on fp32 comparisons, so the ORDER in which a product sums over K must not depend on which
+//     tiling a timing picked, on the batch size or on the box.  Every tiling belongs to one of two
+//     classes, and all tilings of a class produce bit-identical results:
+//       kchains = 1  one fmaf chain over k in the order of the 8-deep groups (k = 8g + {0,4,1,5,2,6,3,7});
+//       kchains = 4  four chains, chain c = the 8-deep groups with g mod 4 == c, summed ((c0+c1)+c2)+c3.
+//                    A workgroup may give the chains to 4, 2 or 1 waves of the same output tile (WK = 4 / 2 /
+//                    1 with NC = 1 / 2 / 4 accumulator sets per wave): small-M products get 4x / 2x the
+//                    wave-level parallelism of one chain without changing a single bit of the result.
+//     The class is chosen by the CALL SITE (engine: 1 for the M = B*N encoder-side products, 4 for the
+//     M = B*k decode-step products), never by the tuner; ovc_gemm_tune only ranks tilings inside it.
+//   * Fifteen tilings (128x128 ... 32x32; K tile 32 or 64); ovc_gemm_tune measures the ones of the requested
+//     class per shape, a cost model covers shapes that were never measured.
+#include <atomic>
+#include <mutex>
 #include <vector>
 
 #include <hip/hip_ext.h>
@@ -39,11 +52,12 @@ namespace {
 // 36 r mod 64 and 68 r mod 64 both hit 16 distinct 4-bank slots for 16 rows distinct mod 16.
 
 // WM x WN x WK waves: the workgroup tile is split WM x WN over the output and, for small tiles, WK ways
-// over K *inside* the workgroup (each wave takes BK/8/WK of the 8-deep k-groups of every K tile; the
-// partial accumulators are summed through LDS at the end).  With M = B*k = 1280 decode rows an output
-// of 1280 x 512 is only 640 MFMA tiles for 1024 SIMDs; splitting K inside 32x32 workgroups turns that
-// into 2560 wave-sized tasks without any cross-workgroup reduction.
-template <int BM, int BN, int WM, int WN, int WK, int BK>
+// over the K chains *inside* the workgroup (wave wk owns chains wk, wk + WK, ...: NC accumulator sets; the
+// chains are summed in chain order through LDS at the end).  With M = B*k = 1280 decode rows an output
+// of 1280 x 512 is only 640 MFMA tiles for 1024 SIMDs; giving the four chains of a 32x32 tile to four waves
+// turns that into 2560 wave-sized tasks without any cross-workgroup reduction.
+// NC * WK = number of chains of the K-order class: 1 (WK = 1, NC = 1) or 4.
+template <int BM, int BN, int WM, int WN, int WK, int BK, int NC>
 struct TileConfig {
     static constexpr int LDT = BK + 4;             // padded LDS row stride (floats)
     static constexpr int kThreads = 256;
@@ -53,12 +67,14 @@ struct TileConfig {
     static constexpr int TN = kWaveN / 32;
     static constexpr int kLoadA = BM * (BK / 4) / kThreads;   // float4 per thread per tile
     static constexpr int kLoadB = BN * (BK / 4) / kThreads;
-    static constexpr int kGroupsPerWave = (BK / 8) / WK;      // 8-deep k-groups per wave per K tile
+    static constexpr int kChains = NC * WK;                   // K-order class of this instance
     static constexpr int kLdsFloats = 2 * (BM + BN) * LDT;
     static_assert(WM * WN * WK == 4, "four waves per workgroup");
+    static_assert(kChains == 1 || kChains == 4, "K-order classes: one chain or four");
+    static_assert(BK % 32 == 0, "a K tile holds whole 4-group periods of the chain assignment");
     static_assert(kWaveM % 32 == 0 && kWaveN % 32 == 0, "wave tile must be a multiple of 32x32");
     static_assert(kLoadA >= 1 && kLoadB >= 1, "tile too small for 256 loader threads");
-    static_assert((WK - 1) * BM * BN <= kLdsFloats, "K-split reduction must fit in the tile buffers");
+    static_assert((WK - 1) * NC * BM * BN <= kLdsFloats, "chain reduction must fit in the tile buffers");
 };
 
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
@@ -68,9 +84,9 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return base + (bid >> 3);
 }
 
-template <int BM, int BN, int WM, int WN, int WK, int BK>
+template <int BM, int BN, int WM, int WN, int WK, int BK, int NC>
 __global__ __launch_bounds__(256) void gemm_f32_mfma(GemmArgs p, int tiles_m, int tiles_n_per_seg, int group_m, int xcd_pm) {
-    using Cfg = TileConfig<BM, BN, WM, WN, WK, BK>;
+    using Cfg = TileConfig<BM, BN, WM, WN, WK, BK, NC>;
     constexpr int LDT = Cfg::LDT;
     constexpr int kVecPerRow = BK / 4;               // float4 per tile row
     constexpr int kRowsPerPass = 256 / kVecPerRow;   // tile rows covered by one pass of the 256 loader threads
@@ -200,13 +216,15 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma(GemmArgs p, int tiles_m, in
         }
     };
 
-    f32x16 acc[Cfg::TM][Cfg::TN];
+    f32x16 acc[NC][Cfg::TM][Cfg::TN];
 #pragma unroll
-    for (int i = 0; i < Cfg::TM; ++i)
+    for (int c = 0; c < NC; ++c)
 #pragma unroll
-        for (int j = 0; j < Cfg::TN; ++j)
+        for (int i = 0; i < Cfg::TM; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            for (int j = 0; j < Cfg::TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[c][i][j][r] = 0.f;
 
     load_tile(0);
     store_tile(0);
@@ -221,9 +239,14 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma(GemmArgs p, int tiles_m, in
 
         const float* a_base = lds + buf * kBufFloats + (wm * Cfg::kWaveM + frag_row) * LDT + frag_k;
         const float* b_base = lds + buf * kBufFloats + (BM + wn * Cfg::kWaveN + frag_row) * LDT + frag_k;
+        // 8-deep k-groups of this K tile, in order.  One chain: every group goes to accumulator set 0.  Four chains:
+        // group kk belongs to chain kk & 3 (K tiles and K slices start on multiples of 32, so this is the global
+        // group index mod 4); this wave owns chains wk + WK * c, kept in set c.
+        constexpr int kGroupsPerWave = Cfg::kChains == 1 ? BK / 8 : (BK / 32) * NC;
 #pragma unroll
-        for (int g = 0; g < Cfg::kGroupsPerWave; ++g) {
-            const int kk = wk * Cfg::kGroupsPerWave + g;
+        for (int g = 0; g < kGroupsPerWave; ++g) {
+            const int set = Cfg::kChains == 1 ? 0 : g % NC;
+            const int kk = Cfg::kChains == 1 ? g : 4 * (g / NC) + wk + WK * (g % NC);
             f32x4 a[Cfg::TM], b[Cfg::TN];
 #pragma unroll
             for (int i = 0; i < Cfg::TM; ++i)
@@ -241,7 +264,7 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma(GemmArgs p, int tiles_m, in
                 for (int i = 0; i < Cfg::TM; ++i)
 #pragma unroll
                     for (int j = 0; j < Cfg::TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][s], b[j][s], acc[i][j], 0, 0, 0);
+                        acc[set][i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][s], b[j][s], acc[set][i][j], 0, 0, 0);
             __builtin_amdgcn_s_setprio(0);
         }
 
@@ -249,31 +272,41 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma(GemmArgs p, int tiles_m, in
         __syncthreads();
     }
 
-    // Intra-workgroup K-split: waves wk > 0 park their partial tiles in LDS (the tile buffers are free
-    // after the last barrier), wave wk == 0 adds them and runs the epilogue.
-    if (WK > 1) {
+    // Chain reduction, always in chain order ((c0 + c1) + c2) + c3 whatever the wave layout: chain c lives in wave
+    // c % WK, accumulator set c / WK.  Waves wk > 0 park their sets in LDS (the tile buffers are free after the last
+    // barrier), wave wk == 0 adds everything up and runs the epilogue.
+    if (Cfg::kChains > 1) {
         float* red = lds;
         const int wtile = wm * WN + wn;
-        if (wk > 0) {
+        auto red_index = [&](int w, int c, int i, int j, int r) {
+            return ((((((w - 1) * NC + c) * (WM * WN) + wtile) * Cfg::TM + i) * Cfg::TN + j) * 16 + r) * 64 + lane;
+        };
+        if (WK > 1) {
+            if (wk > 0) {
 #pragma unroll
-            for (int i = 0; i < Cfg::TM; ++i)
+                for (int c = 0; c < NC; ++c)
 #pragma unroll
-                for (int j = 0; j < Cfg::TN; ++j)
+                    for (int i = 0; i < Cfg::TM; ++i)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        red[((((wk - 1) * (WM * WN) + wtile) * Cfg::TM * Cfg::TN + i * Cfg::TN + j) * 16 + r) * 64 + lane] = acc[i][j][r];
+                        for (int j = 0; j < Cfg::TN; ++j)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) red[red_index(wk, c, i, j, r)] = acc[c][i][j][r];
+            }
+            __syncthreads();
+            if (wk > 0) return;
         }
-        __syncthreads();
-        if (wk > 0) return;
 #pragma unroll
-        for (int s = 0; s < WK - 1; ++s)
+        for (int chain = 1; chain < Cfg::kChains; ++chain) {
+            constexpr int kW = WK;
+            const int w = chain % kW, c = chain / kW;          // compile-time after unrolling
 #pragma unroll
             for (int i = 0; i < Cfg::TM; ++i)
 #pragma unroll
                 for (int j = 0; j < Cfg::TN; ++j)
 #pragma unroll
                     for (int r = 0; r < 16; ++r)
-                        acc[i][j][r] += red[(((s * (WM * WN) + wtile) * Cfg::TM * Cfg::TN + i * Cfg::TN + j) * 16 + r) * 64 + lane];
+                        acc[0][i][j][r] += w == 0 ? acc[c][i][j][r] : red[red_index(w, c, i, j, r)];
+        }
     }
 
     // Epilogue.  D layout of the 32x32 tile: col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
@@ -299,7 +332,7 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma(GemmArgs p, int tiles_m, in
             float out[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float v = acc[i][j][r] + bv;
+                const float v = acc[0][i][j][r] + bv;
                 out[r] = p.act == 1 ? fmaxf(v, 0.f) : v;
             }
             if (has_res) {
@@ -327,27 +360,18 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma(GemmArgs p, int tiles_m, in
     }
 }
 
-// Optional kernel-scoped timing events of the next launch (set by ovc_gemm_launch_timed): with them the launch
-// goes through hipExtLaunchKernelGGL, whose events take the dispatch packet's own begin / end timestamps.
-hipEvent_t g_launch_start = nullptr, g_launch_stop = nullptr;
-// Tuner only: gridDim.z identical copies of the product in one launch (the kernel ignores blockIdx.z), a proxy for
-// "this many batches in flight" that needs no extra streams and no host work between the copies.
-int g_launch_copies = 1;
-int g_tune_copies = 1;      // objective of ovc_gemm_tune: 1 = isolated latency, c > 1 = time of c co-running copies
-
-template <int BM, int BN, int WM, int WN, int WK, int BK>
-int launch_config(const GemmArgs& a, hipStream_t stream) {
-    using Cfg = TileConfig<BM, BN, WM, WN, WK, BK>;
+template <int BM, int BN, int WM, int WN, int WK, int BK, int NC>
+int launch_config(const GemmArgs& a, hipStream_t stream, const GemmLaunchOpts& opts) {
+    using Cfg = TileConfig<BM, BN, WM, WN, WK, BK, NC>;
     const int tiles_m = (a.M + BM - 1) / BM;
     const int tiles_n = (a.seg_n + BN - 1) / BN;
     const int grid = tiles_m * tiles_n * a.nseg;
     const size_t lds_bytes = sizeof(float) * Cfg::kLdsFloats;
-    static bool attr_set = false;   // raise the dynamic-LDS cap once per process (idempotent)
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f32_mfma<BM, BN, WM, WN, WK, BK>),
+    static std::once_flag attr_once;   // raise the dynamic-LDS cap once per process
+    std::call_once(attr_once, [&] {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f32_mfma<BM, BN, WM, WN, WK, BK, NC>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        attr_set = true;
-    }
+    });
     // A panel larger than ~3 MB cannot stay in a 4 MB L2: sweep it in super-rows of 8 M tiles
     const size_t a_bytes = sizeof(float) * (size_t)a.M * (a.K1 + a.K2);
     const int group_m = a_bytes <= (size_t)3 << 20 ? tiles_m : (tiles_m < 8 ? tiles_m : 8);
@@ -364,51 +388,62 @@ int launch_config(const GemmArgs& a, hipStream_t stream) {
             if (cost < best) { best = cost; xcd_pm = pm; }
         }
     }
-    const dim3 grid3(grid, a.ksplit > 1 ? a.ksplit : 1, g_launch_copies);
-    if (g_launch_start && g_launch_stop)
-        hipExtLaunchKernelGGL((gemm_f32_mfma<BM, BN, WM, WN, WK, BK>), grid3, dim3(256), (uint32_t)lds_bytes, stream,
-                              g_launch_start, g_launch_stop, 0, a, tiles_m, tiles_n, group_m, xcd_pm);
+    // opts.copies (tuner only): gridDim.z identical copies of the product in one launch (the kernel ignores
+    // blockIdx.z), a proxy for "this many batches in flight" that needs no extra streams.
+    const dim3 grid3(grid, slices, opts.copies > 1 ? opts.copies : 1);
+    if (opts.start && opts.stop)     // kernel-scoped events: the dispatch packet's own begin / end timestamps
+        hipExtLaunchKernelGGL((gemm_f32_mfma<BM, BN, WM, WN, WK, BK, NC>), grid3, dim3(256), (uint32_t)lds_bytes, stream,
+                              opts.start, opts.stop, 0, a, tiles_m, tiles_n, group_m, xcd_pm);
     else
-        hipLaunchKernelGGL((gemm_f32_mfma<BM, BN, WM, WN, WK, BK>), grid3, dim3(256), lds_bytes, stream, a, tiles_m, tiles_n, group_m, xcd_pm);
+        hipLaunchKernelGGL((gemm_f32_mfma<BM, BN, WM, WN, WK, BK, NC>), grid3, dim3(256), lds_bytes, stream, a, tiles_m, tiles_n, group_m, xcd_pm);
     OVC_RETURN_IF_LAUNCH_FAILED();
     return OVC_OK;
 }
 
-struct TilingInfo { int bm, bn, wk, bk; };
-constexpr TilingInfo kTilings[] = {
-    {128, 128, 1, 32},   // 0
-    {64, 128, 1, 32},    // 1
-    {128, 64, 1, 32},    // 2
-    {64, 64, 1, 32},     // 3
-    {32, 64, 2, 32},     // 4
-    {64, 32, 2, 32},     // 5
-    {32, 32, 4, 32},     // 6
-    {64, 64, 1, 64},     // 7   deeper K tiles: twice the MFMA work per barrier / load round trip
-    {32, 64, 2, 64},     // 8
-    {64, 32, 2, 64},     // 9
-    {32, 32, 4, 64},     // 10
-    {64, 128, 1, 64},    // 11
-};   // (K tiles of 128 were tried for the small tilings: slower -- 15.6 vs 12.2 us on 1280x512x512)
+// bm, bn, wm, wn, wk, bk, nc; chains = wk * nc is the K-order class the instance belongs to
+struct TilingInfo { int bm, bn, wm, wn, wk, bk, nc; };
+#define OVC_TILINGS(X)                                                                                   \
+    /* one chain (kchains = 1) */                                                                        \
+    X(0, 128, 128, 2, 2, 1, 32, 1) X(1, 64, 128, 2, 2, 1, 32, 1) X(2, 128, 64, 2, 2, 1, 32, 1)          \
+    X(3, 64, 64, 2, 2, 1, 32, 1) X(4, 64, 64, 2, 2, 1, 64, 1) X(5, 64, 128, 2, 2, 1, 64, 1)             \
+    /* four chains (kchains = 4): in one wave, in two, in four */                                        \
+    X(6, 64, 128, 2, 2, 1, 32, 4) X(7, 64, 64, 2, 2, 1, 32, 4) X(8, 64, 64, 2, 2, 1, 64, 4)             \
+    X(9, 32, 64, 1, 2, 2, 32, 2) X(10, 64, 32, 2, 1, 2, 32, 2) X(11, 32, 64, 1, 2, 2, 64, 2)            \
+    X(12, 64, 32, 2, 1, 2, 64, 2) X(13, 32, 32, 1, 1, 4, 32, 1) X(14, 32, 32, 1, 1, 4, 64, 1)
+//  (K tiles of 128 were tried for the small tilings: slower -- 15.6 vs 12.2 us on 1280x512x512)
+#define OVC_TILING_INFO(id, bm, bn, wm, wn, wk, bk, nc) {bm, bn, wm, wn, wk, bk, nc},
+constexpr TilingInfo kTilings[] = {OVC_TILINGS(OVC_TILING_INFO)};
+#undef OVC_TILING_INFO
 constexpr int kNumTilings = sizeof(kTilings) / sizeof(kTilings[0]);
+inline int tiling_chains(int t) { return kTilings[t].wk * kTilings[t].nc; }
 
-int g_forced_tiling = -1;   // tuning hook (ovc_debug_force_gemm_tiling); -1 = automatic
+// Debug hook (ovc_debug_force_gemm_tiling): applies to every launch that does not carry its own
+// GemmLaunchOpts::forced_tiling and whose class matches; not for use while other threads decode.
+std::atomic<int> g_forced_tiling{-1};
 
-// Shapes measured by ovc_gemm_tune: (M, seg_n, nseg, K) -> fastest tiling on this device, and (single-segment
-// shapes) the fastest K split with its tiling for callers whose consumer sums partial outputs.
-struct TunedShape { int M, seg_n, nseg, K, tiling, split, split_tiling; };
+// Shapes measured by ovc_gemm_tune: (M, seg_n, nseg, K, kchains, ksplit) -> fastest tiling of that class on this
+// device.  Guarded by g_tuned_mutex (the engine may be driven from several host threads).
+struct TunedShape { int M, seg_n, nseg, K, kchains, ksplit, tiling; };
 std::vector<TunedShape> g_tuned;
+std::mutex g_tuned_mutex;
+std::atomic<int> g_tune_copies{1};      // objective of ovc_gemm_tune: 1 = isolated latency, c > 1 = c co-running copies
+std::atomic<long> g_tune_calls{0};      // measurements actually run (tests assert that bucketed shapes re-use entries)
 
-const TunedShape* tuned_find(int M, int seg_n, int nseg, int K) {
-    for (const TunedShape& t : g_tuned)
-        if (t.M == M && t.seg_n == seg_n && t.nseg == nseg && t.K == K) return &t;
-    return nullptr;
-}
-
-int tuned_lookup(const GemmArgs& a) {
-    const TunedShape* t = tuned_find(a.M, a.seg_n, a.nseg, a.K1 + a.K2);
-    if (!t) return -1;
-    if (a.ksplit > 1) return t->split == a.ksplit ? t->split_tiling : -1;
-    return t->tiling;
+// Exact entry, or (near = true) the entry of the same product whose M is closest within a factor of two: the best
+// tiling moves slowly with M, and every tiling of a class gives the same bits, so borrowing a neighbour's choice
+// costs at most a little speed.  Batches whose region count varies (M = B*N) then never wait for a tuning run.
+int tuned_lookup(int M, int seg_n, int nseg, int K, int kchains, int ksplit, bool near) {
+    std::lock_guard<std::mutex> lock(g_tuned_mutex);
+    int best = -1;
+    double best_ratio = 2.0;
+    for (const TunedShape& t : g_tuned) {
+        if (t.seg_n != seg_n || t.nseg != nseg || t.K != K || t.kchains != kchains || t.ksplit != ksplit) continue;
+        if (t.M == M) return t.tiling;
+        if (!near) continue;
+        const double ratio = t.M > M ? (double)t.M / M : (double)M / t.M;
+        if (ratio <= best_ratio) { best_ratio = ratio; best = t.tiling; }
+    }
+    return best;
 }
 
 // Predicted time of a tiling in MFMA-issue units (one unit = one v_mfma_f32_32x32x2_f32 slot of a
@@ -421,41 +456,46 @@ double tiling_cost(const GemmArgs& a, const TilingInfo& t) {
     const long wgs = (long)((a.M + t.bm - 1) / t.bm) * ((a.seg_n + t.bn - 1) / t.bn) * a.nseg;
     const double per_cu = (double)((wgs + 255) / 256);                       // workgroups on the busiest CU
     const double mfma_per_wave = (double)(t.bm / 32) * (t.bn / 32) * (K / 2.0) / 4.0;
-    const double overhead = 48.0 + (t.bk >= 64 ? 1e9 : 0.0);                 // BK=64 tilings: only when forced (tuning)
+    const double overhead = 48.0 + (t.bk >= 64 ? 1e9 : 0.0);                 // BK=64 tilings: only when measured or forced
     const double bytes_per_flop = 2.0 * (t.bm + t.bn) / (double)(t.bm * t.bn);   // operand floats per MAC
     const double bw_penalty = 1.0 + 4.0 * bytes_per_flop;                    // 128x128: 1.06, 32x32: 1.5
     return per_cu * (mfma_per_wave * bw_penalty + overhead);
 }
 
-}  // namespace
+int args_chains(const GemmArgs& a) { return a.kchains == 4 ? 4 : 1; }
 
-extern "C" int ovc_debug_force_gemm_tiling(int tiling) {
-    if (tiling < -1 || tiling >= kNumTilings) return OVC_EINVAL;
-    g_forced_tiling = tiling;
-    return OVC_OK;
-}
-
-const char* ovc_gemm_tiling_name(int tiling) {
-    static const char* names[] = {"gemm_f32_mfma<128, 128, 2, 2, 1, 32>", "gemm_f32_mfma<64, 128, 2, 2, 1, 32>",
-                                  "gemm_f32_mfma<128, 64, 2, 2, 1, 32>", "gemm_f32_mfma<64, 64, 2, 2, 1, 32>",
-                                  "gemm_f32_mfma<32, 64, 1, 2, 2, 32>", "gemm_f32_mfma<64, 32, 2, 1, 2, 32>",
-                                  "gemm_f32_mfma<32, 32, 1, 1, 4, 32>", "gemm_f32_mfma<64, 64, 2, 2, 1, 64>",
-                                  "gemm_f32_mfma<32, 64, 1, 2, 2, 64>", "gemm_f32_mfma<64, 32, 2, 1, 2, 64>",
-                                  "gemm_f32_mfma<32, 32, 1, 1, 4, 64>", "gemm_f32_mfma<64, 128, 2, 2, 1, 64>"};
-    return tiling >= 0 && tiling < kNumTilings ? names[tiling] : "";
-}
-
-// A tiling fits a problem when no tile straddles two N segments and the A1|A2 seam falls on a K-tile boundary.
-static bool tiling_fits(const GemmArgs& a, int t) {
+// A tiling fits a problem when it belongs to the problem's K-order class, no tile straddles two N segments and the
+// A1|A2 seam / the K slices fall on K-tile boundaries.
+bool tiling_fits(const GemmArgs& a, int t) {
+    if (tiling_chains(t) != args_chains(a)) return false;
     if (a.nseg > 1 && a.seg_n % kTilings[t].bn) return false;
     if (a.K2 > 0 && a.K1 % kTilings[t].bk) return false;
     if (a.ksplit > 1 && (a.K1 / a.ksplit) % kTilings[t].bk) return false;     // a slice is a whole number of K tiles
     return true;
 }
 
-int ovc_gemm_pick_tiling(const GemmArgs& a) {
-    if (g_forced_tiling >= 0 && tiling_fits(a, g_forced_tiling)) return g_forced_tiling;
-    const int tuned = tuned_lookup(a);
+}  // namespace
+
+extern "C" int ovc_debug_force_gemm_tiling(int tiling) {
+    if (tiling < -1 || tiling >= kNumTilings) return OVC_EINVAL;
+    g_forced_tiling.store(tiling);
+    return OVC_OK;
+}
+
+const char* ovc_gemm_tiling_name(int tiling) {
+#define OVC_TILING_NAME(id, bm, bn, wm, wn, wk, bk, nc) "gemm_f32_mfma<" #bm ", " #bn ", " #wm ", " #wn ", " #wk ", " #bk ", " #nc ">",
+    static const char* names[] = {OVC_TILINGS(OVC_TILING_NAME)};
+#undef OVC_TILING_NAME
+    return tiling >= 0 && tiling < kNumTilings ? names[tiling] : "";
+}
+
+int ovc_gemm_tiling_class(int tiling) { return tiling >= 0 && tiling < kNumTilings ? tiling_chains(tiling) : 0; }
+
+int ovc_gemm_pick_tiling(const GemmArgs& a, const GemmLaunchOpts& opts) {
+    if (opts.forced_tiling >= 0) return opts.forced_tiling < kNumTilings && tiling_fits(a, opts.forced_tiling) ? opts.forced_tiling : -1;
+    const int forced = g_forced_tiling.load();
+    if (forced >= 0 && tiling_fits(a, forced)) return forced;
+    const int tuned = tuned_lookup(a.M, a.seg_n, a.nseg, a.K1 + a.K2, args_chains(a), a.ksplit > 1 ? a.ksplit : 1, true);
     if (tuned >= 0 && tiling_fits(a, tuned)) return tuned;
     double best = 1e300;
     int pick = -1;
@@ -467,16 +507,10 @@ int ovc_gemm_pick_tiling(const GemmArgs& a) {
     return pick;
 }
 
-int ovc_gemm_launch_timed(const GemmArgs& a, hipStream_t stream, hipEvent_t start, hipEvent_t stop) {
-    g_launch_start = start; g_launch_stop = stop;
-    const int rc = ovc_gemm_launch(a, stream);
-    g_launch_start = nullptr; g_launch_stop = nullptr;
-    return rc;
-}
-
-int ovc_gemm_launch(const GemmArgs& a, hipStream_t stream) {
+int ovc_gemm_launch(const GemmArgs& a, hipStream_t stream, const GemmLaunchOpts& opts) {
     const int K = a.K1 + a.K2;
     if (a.M <= 0 || a.seg_n <= 0 || a.nseg <= 0 || a.nseg > OVC_MAX_SEGMENTS || K <= 0) return OVC_EINVAL;
+    if (a.kchains != 0 && a.kchains != 1 && a.kchains != 4) return OVC_EINVAL;
     if ((a.K1 & 3) || (a.K2 & 3) || (a.lda1 & 3) || (a.K2 && (a.lda2 & 3))) return OVC_EINVAL;
     if (!ovc_aligned16(a.A1) || (a.K2 && !a.A2 && !a.seg[0].A2) || (a.A2 && !ovc_aligned16(a.A2))) return OVC_EINVAL;
     for (int s = 0; s < a.nseg; ++s)
@@ -499,113 +533,89 @@ int ovc_gemm_launch(const GemmArgs& a, hipStream_t stream) {
         (long)(a.seg_n + 256) * K * 4 > kMaxBytes || (long)(a.M + 256) * a.ldc * 4 > kMaxBytes ||
         (a.R && (long)(a.M + 256) * a.ldr * 4 > kMaxBytes)) return OVC_EINVAL;
 
-    const int pick = ovc_gemm_pick_tiling(a);
+    const int pick = ovc_gemm_pick_tiling(a, opts);
     switch (pick) {
-        case 0: return launch_config<128, 128, 2, 2, 1, 32>(a, stream);
-        case 1: return launch_config<64, 128, 2, 2, 1, 32>(a, stream);
-        case 2: return launch_config<128, 64, 2, 2, 1, 32>(a, stream);
-        case 3: return launch_config<64, 64, 2, 2, 1, 32>(a, stream);
-        case 4: return launch_config<32, 64, 1, 2, 2, 32>(a, stream);
-        case 5: return launch_config<64, 32, 2, 1, 2, 32>(a, stream);
-        case 6: return launch_config<32, 32, 1, 1, 4, 32>(a, stream);
-        case 7: return launch_config<64, 64, 2, 2, 1, 64>(a, stream);
-        case 8: return launch_config<32, 64, 1, 2, 2, 64>(a, stream);
-        case 9: return launch_config<64, 32, 2, 1, 2, 64>(a, stream);
-        case 10: return launch_config<32, 32, 1, 1, 4, 64>(a, stream);
-        case 11: return launch_config<64, 128, 2, 2, 1, 64>(a, stream);
+#define OVC_TILING_CASE(id, bm, bn, wm, wn, wk, bk, nc) case id: return launch_config<bm, bn, wm, wn, wk, bk, nc>(a, stream, opts);
+        OVC_TILINGS(OVC_TILING_CASE)
+#undef OVC_TILING_CASE
         default: return OVC_EINVAL;
     }
 }
 
-// Measure every tiling on one GEMM shape and remember the fastest (process-wide).  Synchronises the
-// stream: call it at set-up time, never inside a captured or latency-sensitive region.
-extern "C" int ovc_gemm_tune(int M, int seg_n, int nseg, int K, void* scratch, size_t scratch_bytes, ovc_stream stream) {
+// Measure every tiling of one K-order class on one GEMM shape and remember the fastest (process-wide).  Synchronises
+// the stream: call it at set-up time, never inside a captured or latency-sensitive region.  The choice changes speed
+// only: all tilings of a class produce the same bits.
+extern "C" int ovc_gemm_tune(int M, int seg_n, int nseg, int K, int kchains, int ksplit, void* scratch, size_t scratch_bytes,
+                             ovc_stream stream) {
     if (M <= 0 || seg_n <= 0 || nseg <= 0 || nseg > OVC_MAX_SEGMENTS || K <= 0 || (K & 3)) return OVC_EINVAL;
+    if ((kchains != 1 && kchains != 4) || ksplit < 1 || ksplit > kMaxKSplit || (ksplit > 1 && (nseg != 1 || K % (ksplit * 32)))) return OVC_EINVAL;
     const size_t na = (size_t)M * K, nw = (size_t)seg_n * nseg * K, nc = (size_t)M * seg_n * nseg;
-    if (!scratch || scratch_bytes < sizeof(float) * (na + nw + nc) || !ovc_aligned16(scratch)) return OVC_EWORKSPACE;
+    if (!scratch || !ovc_aligned16(scratch)) return OVC_EWORKSPACE;
     if (nseg > 1 && seg_n % 64) return OVC_EINVAL;
     float* A = reinterpret_cast<float*>(scratch);
     float* W = A + ((na + 3) & ~(size_t)3);
     float* C = W + ((nw + 3) & ~(size_t)3);
-    if ((size_t)(C - A) + nc > scratch_bytes / sizeof(float)) return OVC_EWORKSPACE;
+    if ((size_t)(C - A) + (size_t)ksplit * nc > scratch_bytes / sizeof(float)) return OVC_EWORKSPACE;
+    if (tuned_lookup(M, seg_n, nseg, K, kchains, ksplit, false) >= 0) return OVC_OK;
     GemmArgs a{};
-    a.A1 = A; a.lda1 = K; a.K1 = K; a.M = M; a.seg_n = seg_n; a.nseg = nseg; a.ldc = seg_n;
-    for (int s = 0; s < nseg; ++s) a.seg[s] = GemmSegment{W + (size_t)s * seg_n * K, nullptr, C + (size_t)s * M * seg_n};
-    if (tuned_find(M, seg_n, nseg, K)) return OVC_OK;
+    a.A1 = A; a.lda1 = K; a.K1 = K; a.M = M; a.seg_n = seg_n; a.nseg = nseg; a.ldc = seg_n; a.kchains = kchains;
+    if (ksplit > 1) { a.ksplit = ksplit; a.part_stride = (long)nc; }
+    for (int s = 0; s < nseg; ++s) a.seg[s] = GemmSegment{W + (size_t)s * seg_n * K, nullptr, C + (size_t)s * M * seg_n, nullptr};
     hipStream_t st = ovc_hip_stream(stream);
     hipEvent_t e0, e1;
     if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return OVC_ELAUNCH;
-    const int saved = g_forced_tiling;
-    int rc = OVC_OK;
-    g_launch_copies = g_tune_copies;
-    // fastest tiling of `a` (plain or K-split), -1 when nothing fits
-    auto fastest = [&](const GemmArgs& g, float* best_ms) {
-        int best = -1;
-        *best_ms = 1e30f;
-        for (int t = 0; t < kNumTilings && rc == OVC_OK; ++t) {
-            if (!tiling_fits(g, t)) continue;
-            g_forced_tiling = t;
-            for (int i = 0; i < 2 && rc == OVC_OK; ++i) rc = ovc_gemm_launch(g, st);
-            (void)hipEventRecord(e0, st);
-            for (int i = 0; i < 6 && rc == OVC_OK; ++i) rc = ovc_gemm_launch(g, st);
-            (void)hipEventRecord(e1, st);
-            if (hipEventSynchronize(e1) != hipSuccess) rc = OVC_ELAUNCH;
-            float ms = 0.f;
-            if (rc == OVC_OK && hipEventElapsedTime(&ms, e0, e1) == hipSuccess && ms < *best_ms) { *best_ms = ms; best = t; }
-        }
-        return best;
-    };
-    float plain_ms = 0.f;
-    const int plain = fastest(a, &plain_ms);
-    // K splits for single-segment shapes, as far as the scratch holds the partial outputs; a split must beat the
-    // plain product by 5 % to be chosen (its consumer reads `split` times the output)
-    int split = 1, split_tiling = -1;
-    float split_ms = plain_ms * 0.95f;
-    // (only shapes with few output tiles can gain: with >= 1024 tiles of 64x64 the plain product already fills the chip)
-    const bool few_tiles = (long)((M + 63) / 64) * ((seg_n + 63) / 64) < 1024;
-    for (int s = 2; s <= kMaxKSplit && nseg == 1 && few_tiles && rc == OVC_OK; s *= 2) {
-        if (K % (s * 32) || (size_t)(C - A) + (size_t)s * nc > scratch_bytes / sizeof(float)) continue;
-        GemmArgs g = a;
-        g.ksplit = s; g.part_stride = (long)nc;
+    int rc = OVC_OK, best = -1;
+    float best_ms = 1e30f;
+    GemmLaunchOpts opts{};
+    opts.copies = g_tune_copies.load();
+    for (int t = 0; t < kNumTilings && rc == OVC_OK; ++t) {
+        if (!tiling_fits(a, t)) continue;
+        opts.forced_tiling = t;
+        for (int i = 0; i < 2 && rc == OVC_OK; ++i) rc = ovc_gemm_launch(a, st, opts);
+        (void)hipEventRecord(e0, st);
+        for (int i = 0; i < 6 && rc == OVC_OK; ++i) rc = ovc_gemm_launch(a, st, opts);
+        (void)hipEventRecord(e1, st);
+        if (hipEventSynchronize(e1) != hipSuccess) rc = OVC_ELAUNCH;
         float ms = 0.f;
-        const int t = fastest(g, &ms);
-        if (t >= 0 && ms < split_ms) { split_ms = ms; split = s; split_tiling = t; }
+        if (rc == OVC_OK && hipEventElapsedTime(&ms, e0, e1) == hipSuccess && ms < best_ms) { best_ms = ms; best = t; }
     }
-    g_forced_tiling = saved;
-    g_launch_copies = 1;
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    g_tune_calls.fetch_add(1);
     if (rc != OVC_OK) return rc;
-    if (plain >= 0) g_tuned.push_back(TunedShape{M, seg_n, nseg, K, plain, split, split_tiling});
+    if (best >= 0) {
+        std::lock_guard<std::mutex> lock(g_tuned_mutex);
+        g_tuned.push_back(TunedShape{M, seg_n, nseg, K, kchains, ksplit, best});
+    }
     return OVC_OK;
 }
 
 extern "C" int ovc_gemm_tune_objective(int copies) {
     if (copies < 1 || copies > 8) return OVC_EINVAL;
-    g_tune_copies = copies;
+    g_tune_copies.store(copies);
     return OVC_OK;
 }
 
-// Tuned entry as one integer: tiling | split << 8 | split_tiling << 16 (split 1 = no K split); -1 = not tuned.
-extern "C" int ovc_gemm_tuned_get(int M, int seg_n, int nseg, int K) {
-    const TunedShape* t = tuned_find(M, seg_n, nseg, K);
-    return t ? (t->tiling | t->split << 8 | (t->split > 1 ? t->split_tiling : 0) << 16) : -1;
+extern "C" long ovc_gemm_tune_calls(void) { return g_tune_calls.load(); }
+
+// Remembered tiling of a shape: -1 = nothing usable.  near != 0 also accepts the entry of the same product with the
+// closest M within a factor of two (what the launch path itself falls back to).
+extern "C" int ovc_gemm_tuned_get(int M, int seg_n, int nseg, int K, int kchains, int ksplit, int near) {
+    return tuned_lookup(M, seg_n, nseg, K, kchains == 4 ? 4 : 1, ksplit > 1 ? ksplit : 1, near != 0);
 }
 
-extern "C" int ovc_gemm_tuned_set(int M, int seg_n, int nseg, int K, int code) {
-    const int tiling = code & 0xff, split = (code >> 8) & 0xff, split_tiling = (code >> 16) & 0xff;
-    if (code < 0 || tiling >= kNumTilings || (nseg > 1 && seg_n % kTilings[tiling].bn)) return OVC_EINVAL;
-    if (split > 1 && (split > kMaxKSplit || nseg != 1 || K % (split * kTilings[split_tiling < kNumTilings ? split_tiling : 0].bk) ||
-                      split_tiling >= kNumTilings)) return OVC_EINVAL;
-    const TunedShape entry{M, seg_n, nseg, K, tiling, split > 1 ? split : 1, split > 1 ? split_tiling : -1};
+extern "C" int ovc_gemm_tuned_set(int M, int seg_n, int nseg, int K, int kchains, int ksplit, int tiling) {
+    if (tiling < 0 || tiling >= kNumTilings || (kchains != 1 && kchains != 4) || ksplit < 1 || ksplit > kMaxKSplit) return OVC_EINVAL;
+    if (M <= 0 || seg_n <= 0 || nseg <= 0 || nseg > OVC_MAX_SEGMENTS || K <= 0) return OVC_EINVAL;
+    GemmArgs a{};
+    a.M = M; a.seg_n = seg_n; a.nseg = nseg; a.K1 = K; a.kchains = kchains; a.ksplit = ksplit;
+    if (ksplit > 1 && (nseg != 1 || K % (ksplit * 32))) return OVC_EINVAL;
+    if (!tiling_fits(a, tiling)) return OVC_EINVAL;           // wrong class, tile straddling a segment, slice not a whole K tile
+    const TunedShape entry{M, seg_n, nseg, K, kchains, ksplit, tiling};
+    std::lock_guard<std::mutex> lock(g_tuned_mutex);
     for (TunedShape& t : g_tuned)
-        if (t.M == M && t.seg_n == seg_n && t.nseg == nseg && t.K == K) { t = entry; return OVC_OK; }
+        if (t.M == M && t.seg_n == seg_n && t.nseg == nseg && t.K == K && t.kchains == kchains && t.ksplit == ksplit) { t = entry; return OVC_OK; }
     g_tuned.push_back(entry);
     return OVC_OK;
-}
-
-int ovc_gemm_split_for(int M, int N, int K) {
-    const TunedShape* t = tuned_find(M, N, 1, K);
-    return t && t->split > 1 ? t->split : 1;
 }
 
 // Tuning helper: `iters` back-to-back launches of one GEMM on `stream` (no host work in between).
@@ -613,12 +623,29 @@ extern "C" int ovc_debug_repeat_linear(const float* x, int K, const float* W, co
                                        int iters, ovc_stream stream) {
     GemmArgs a{};
     a.A1 = x; a.lda1 = K; a.K1 = K; a.M = M; a.seg_n = N; a.nseg = 1; a.ldc = N; a.act = 0;
-    a.seg[0] = GemmSegment{W, bias, y};
+    const int forced = g_forced_tiling.load();
+    a.kchains = forced >= 0 ? tiling_chains(forced) : 1;      // follow a forced tiling's class
+    a.seg[0] = GemmSegment{W, bias, y, nullptr};
     for (int i = 0; i < iters; ++i) {
-        const int rc = ovc_gemm_launch(a, ovc_hip_stream(stream));
+        const int rc = ovc_gemm_launch(a, ovc_hip_stream(stream), GemmLaunchOpts{});
         if (rc != OVC_OK) return rc;
     }
     return OVC_OK;
+}
+
+// y = x W^T + bias computed by one named tiling (its class follows from the tiling): the parity tests use it to
+// show that all tilings of a class give the same bits.  ksplit > 1: y receives `ksplit` raw partial products
+// [ksplit][M][N] (no bias).
+extern "C" int ovc_debug_linear_tiling(const float* x, int K, const float* W, const float* bias, float* y, int M, int N,
+                                       int tiling, int ksplit, ovc_stream stream) {
+    if (tiling < 0 || tiling >= kNumTilings || !x || !W || !y) return OVC_EINVAL;
+    GemmArgs a{};
+    a.A1 = x; a.lda1 = K; a.K1 = K; a.M = M; a.seg_n = N; a.nseg = 1; a.ldc = N; a.kchains = tiling_chains(tiling);
+    a.seg[0] = GemmSegment{W, ksplit > 1 ? nullptr : bias, y, nullptr};
+    if (ksplit > 1) { a.ksplit = ksplit; a.part_stride = (long)M * N; }
+    GemmLaunchOpts opts{};
+    opts.forced_tiling = tiling;
+    return ovc_gemm_launch(a, ovc_hip_stream(stream), opts);
 }
 
 extern "C" int ovc_linear(const float* x, int ldx, const float* x2, int ldx2, int K1, int K2,
@@ -630,6 +657,7 @@ extern "C" int ovc_linear(const float* x, int ldx, const float* x2, int ldx2, in
     a.A2 = K2 > 0 ? x2 : nullptr; a.lda2 = ldx2; a.K2 = K2 > 0 ? K2 : 0;
     a.M = M; a.seg_n = N; a.nseg = 1; a.ldc = ldy;
     a.R = residual; a.ldr = ldr; a.act = act;
-    a.seg[0] = GemmSegment{W, bias, y};
-    return ovc_gemm_launch(a, ovc_hip_stream(stream));
+    a.kchains = 1;                                       // operator level: one chain, whatever the shape
+    a.seg[0] = GemmSegment{W, bias, y, nullptr};
+    return ovc_gemm_launch(a, ovc_hip_stream(stream), GemmLaunchOpts{});
 }

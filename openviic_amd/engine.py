@@ -2,8 +2,14 @@
 
 ``CaptionEngine`` reads the parameter tensors of a host-side model (``architectures.py``) into the
 ``ovc_model`` pointer table once, owns one cached device workspace per HIP stream and forwards
-calls on the current stream -- independent batches issued on different streams overlap on the GPU.  Parameters are referenced, not copied: in-place updates of the tensors are seen by
-the engine; re-allocation (``.to()``) drops the engine (``BaseTransformer._apply``).
+calls on the current stream -- independent batches issued on different streams overlap on the GPU.
+Parameters are referenced, not copied: in-place updates of the tensors (``load_state_dict``, an
+optimizer step) are seen by the engine; the one derived buffer (the geometric encoder's stacked
+``fc_gs``) is refreshed from the live parameters on every call; re-allocation (``.to()``) drops the
+engine (``BaseTransformer._apply``).
+
+Numerics never depend on a timing: the order in which every GEMM sums over K is fixed per call site
+(``csrc/gemm.hip``, K-order classes), the tiling measurement below only ranks bit-identical tilings.
 """
 import ctypes
 import json
@@ -58,11 +64,15 @@ class CaptionEngine:
     tune_concurrency = int(os.environ.get("OVC_TUNE_CONCURRENCY", "1"))
     # replay the decode launch sequence as a hipGraph from the third call of a shape on (OVC_GRAPH=0: plain launches)
     use_graph = os.environ.get("OVC_GRAPH", "1") != "0"
+    # pad the region axis to a multiple of this with zero rows before decoding (1 = exact shapes).  Results are
+    # identical; with ragged real-data batches a bucket of 8 or 16 bounds the number of distinct shapes (graphs).
+    region_bucket = int(os.environ.get("OVC_REGION_BUCKET", "1"))
 
     def __init__(self, model):
         self.lib = native.load()
         self.model = model
         self._keep = []          # tensors created here whose storage the pointer table references
+        self._fc_g = None
         self.desc = self._describe(model)
         self._workspaces = {}    # one scratch buffer per HIP stream: concurrent batches never share state
         self._tuned = set()
@@ -97,8 +107,11 @@ class CaptionEngine:
         _norm(d.enc_ln, enc.layer_norm)
         if d.enc_kind == native.ENC_GEOMETRIC:
             d.trig, d.d_g = int(bool(enc.trignometric_embedding)), enc.d_g
+            # the box-relation kernel wants the per-head Linear(d_g, 1) layers stacked: the only parameters the
+            # engine holds as a COPY, re-filled from the live tensors by _refresh_derived() on every call
             w = torch.cat([fc.weight.detach() for fc in enc.fc_gs], dim=0).contiguous()
             b = torch.cat([fc.bias.detach() for fc in enc.fc_gs], dim=0).contiguous()
+            self._fc_g = (w, b)
             self._keep += [w, b]
             d.fc_g_w, d.fc_g_b = _p(w), _p(b)
         for i, layer in enumerate(enc.layers):
@@ -116,39 +129,38 @@ class CaptionEngine:
         d.fc = _p(dec.fc.weight.detach())
         return d
 
+    def _refresh_derived(self):
+        """Re-fill the stacked ``fc_gs`` copy from the live parameters (h * d_g floats, on the current stream): a
+        ``load_state_dict`` or an optimizer step between two calls must not leave the engine on stale weights."""
+        if self._fc_g is not None:
+            enc = self.model.encoder
+            torch.cat([fc.weight.detach() for fc in enc.fc_gs], dim=0, out=self._fc_g[0])
+            torch.cat([fc.bias.detach() for fc in enc.fc_gs], dim=0, out=self._fc_g[1])
+
     # -- GEMM tiling selection ------------------------------------------------------------------
     def gemm_shapes(self, B, N, k):
-        """(M, seg_n, nseg, K) of every GEMM the engine issues for batch B, N regions, beam k."""
-        d = self.desc
-        dm, hk, hv, ff, L = d.d_model, d.heads * d.d_k, d.heads * d.d_v, d.d_ff, d.n_dec
-        shapes = set()
-        bn = B * N
-        shapes.add((bn, dm, 1, d.d_feat))
-        shapes.update({(bn, hk, 3, dm), (bn, dm, 1, hv), (bn, ff, 1, dm), (bn, dm, 1, ff)})
-        for l0 in range(0, L, 4):
-            shapes.add((bn, hk, 2 * min(4, L - l0), dm))
-        for rows in {B, B * k}:
-            shapes.update({(rows, hk, 3, dm), (rows, dm, 1, hv), (rows, hk, 1, dm), (rows, ff, 1, dm),
-                           (rows, dm, 1, ff), (rows, d.vocab, 1, dm)})
-            if d.dec_kind == native.DEC_MESHED:
-                shapes.add((rows, dm, d.n_levels if dm % 64 == 0 else 1, 2 * dm))      # level gates, one segment per level
-                shapes.add((rows * d.n_levels, dm, 1, hv))           # shared output projection over the stacked levels
-        for rows, aoa in ((bn, self.model.encoder.layers[0].mhatt.use_aoa),
-                          (B, self.model.decoder.layers[0].self_attn.use_aoa),
-                          (B * k, self.model.decoder.layers[0].self_attn.use_aoa)):
-            if aoa:
-                shapes.add((rows, dm, 2 if dm % 64 == 0 else 1, 2 * dm))
-        return sorted(shapes)
+        """(M, seg_n, nseg, K, kchains, ksplit) of every GEMM the engine issues for batch B, N regions, beam k --
+        enumerated by the library itself (``ovc_engine_gemm_shapes`` walks the real launch sequence in dry mode)."""
+        cap = 64
+        while True:
+            buf = (ctypes.c_int32 * (6 * cap))()
+            n = self.lib.ovc_engine_gemm_shapes(ctypes.byref(self.desc), B, N, k, buf, cap)
+            check(min(n, 0), "ovc_engine_gemm_shapes")
+            if n <= cap:
+                return sorted(tuple(buf[6 * i + j] for j in range(6)) for i in range(n))
+            cap = n
 
     def tune(self, B, N, k):
-        """Time every GEMM tiling on the engine's shapes once (synchronises; ~0.2 s) and let the
-        library remember the fastest per shape."""
+        """Time the GEMM tilings of each of the engine's (shape, K-order class) once and let the library remember the
+        fastest (synchronises; ~0.2 s).  Speed only: all tilings of a class give the same bits.  Shapes for which the
+        library already holds an entry with M within a factor of two (another region count or batch size) are not
+        measured again, so batches with varying N never wait here after the first one."""
         key = (B, N, k)
         if key in self._tuned:
             return
         shapes = self.gemm_shapes(B, N, k)
         objective = max(1, min(8, int(self.tune_concurrency)))
-        cache_path = os.environ.get("OVC_TUNE_CACHE")       # optional json: {"M,seg_n,nseg,K@objective": ovc_gemm_tuned_get code}
+        cache_path = os.environ.get("OVC_TUNE_CACHE")       # optional json: {"M,seg_n,nseg,K,kchains,ksplit@objective": tiling}
         cache = {}
         if cache_path and os.path.exists(cache_path):
             with open(cache_path) as f:
@@ -157,19 +169,22 @@ class CaptionEngine:
                 name = ",".join(map(str, shape)) + "@%d" % objective
                 if name in cache:
                     self.lib.ovc_gemm_tuned_set(*shape, int(cache[name]))
-        check(self.lib.ovc_gemm_tune_objective(objective), "ovc_gemm_tune_objective")
-        # operands + output; single-segment shapes also hold the partial outputs of a 4-way K split
-        need = max(4 * (m * kk + sn * ns * kk + m * sn * ns * (4 if ns == 1 and m * sn < 4 << 20 else 1)) + 256
-                   for m, sn, ns, kk in shapes)
-        scratch = torch.empty(need // 4 + 16, dtype=torch.float32, device=self.device).normal_()
-        for m, sn, ns, kk in shapes:
-            check(self.lib.ovc_gemm_tune(m, sn, ns, kk, scratch.data_ptr(), scratch.numel() * 4, native.stream_handle()),
-                  "ovc_gemm_tune{}".format((m, sn, ns, kk)))
-        torch.cuda.current_stream().synchronize()
+        todo = [sh for sh in shapes if self.lib.ovc_gemm_tuned_get(*sh, 1) < 0]
+        if todo:
+            check(self.lib.ovc_gemm_tune_objective(objective), "ovc_gemm_tune_objective")
+            # operands + output (K-split shapes: one partial output per slice)
+            need = max(4 * (m * kk + sn * ns * kk + m * sn * ns * ks) + 256 for m, sn, ns, kk, _, ks in todo)
+            scratch = torch.empty(need // 4 + 16, dtype=torch.float32, device=self.device).normal_()
+            for sh in todo:
+                check(self.lib.ovc_gemm_tune(*sh, scratch.data_ptr(), scratch.numel() * 4, native.stream_handle()),
+                      "ovc_gemm_tune{}".format(sh))
+            torch.cuda.current_stream().synchronize()
         self._tuned.add(key)
-        if cache_path:
+        if cache_path and todo:
             for shape in shapes:
-                cache[",".join(map(str, shape)) + "@%d" % objective] = self.lib.ovc_gemm_tuned_get(*shape)
+                t = self.lib.ovc_gemm_tuned_get(*shape, 0)
+                if t >= 0:
+                    cache[",".join(map(str, shape)) + "@%d" % objective] = t
             os.makedirs(os.path.dirname(os.path.abspath(cache_path)), exist_ok=True)
             with open(cache_path, "w") as f:
                 json.dump(cache, f, indent=0, sort_keys=True)
@@ -183,9 +198,44 @@ class CaptionEngine:
         key = torch.cuda.current_stream().cuda_stream
         ws = self._workspaces.get(key)
         if ws is None or ws.numel() < need:
-            self._workspaces.pop(key, None)
-            ws = self._workspaces[key] = torch.empty(need, dtype=torch.uint8, device=self.device)
+            old = self._workspaces.pop(key, None)
+            if old is not None:
+                # captured graphs reference the old buffer's addresses: drop them before it is freed
+                self.lib.ovc_graph_cache_drop_workspace(old.data_ptr())
+            # grow geometrically so that a slowly increasing region count does not re-allocate (and re-capture) every time
+            size = need if old is None else max(need, int(old.numel() * 1.25))
+            ws = self._workspaces[key] = torch.empty(size, dtype=torch.uint8, device=self.device)
         return ws, need
+
+    def release(self):
+        """Drop this engine's workspaces and the hipGraphs captured on them."""
+        lib = getattr(self, "lib", None)
+        for ws in getattr(self, "_workspaces", {}).values():
+            if lib is not None:
+                lib.ovc_graph_cache_drop_workspace(ws.data_ptr())
+        self._workspaces = {}
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:       # interpreter shutdown: the library or torch may already be gone
+            pass
+
+    def _bucketed(self, features, boxes):
+        """Pad the region axis up to a multiple of ``region_bucket`` with all-zero rows.  Exact: a zero feature row IS
+        the reference's padding (``utils/instance.py:156-171`` pads ragged batches the same way, ``models/utils.py:48-61``
+        masks such rows as keys, positions are indexed by region), and every GEMM sums K in a shape-independent order.
+        Fewer distinct N means fewer captured graphs when the region count varies from batch to batch."""
+        bucket = max(1, int(self.region_bucket))
+        N = features.shape[1]
+        target = min(128, -(-N // bucket) * bucket)
+        if target == N:
+            return features, boxes
+        pad = target - N
+        features = torch.nn.functional.pad(features, (0, 0, 0, pad))
+        if boxes is not None:
+            boxes = torch.nn.functional.pad(boxes, (0, 0, 0, pad))
+        return features, boxes
 
     @staticmethod
     def _features(x, name):
@@ -197,6 +247,7 @@ class CaptionEngine:
     def encode(self, features, boxes=None):
         features, boxes = self._checked_inputs(features, boxes)
         B, N = features.shape[:2]
+        self._refresh_derived()
         ws, need = self._get_workspace(B, N, 1, False)
         d = self.desc
         shape = (B, d.n_levels, N, d.d_model) if d.enc_kind == native.ENC_MULTILEVEL else (B, N, d.d_model)
@@ -222,9 +273,11 @@ class CaptionEngine:
 
     def beam_search(self, features, boxes, batch_size, beam_size, out_size=1, return_probs=False):
         features, boxes = self._checked_inputs(features, boxes)
+        features, boxes = self._bucketed(features, boxes)
         B, N = features.shape[:2]
         if B != batch_size:
             raise native.OvcError("batch_size={} but features hold {} images".format(batch_size, B))
+        self._refresh_derived()
         d = self.desc
         T, V = d.max_len, d.vocab
         if self.autotune:

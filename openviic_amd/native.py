@@ -12,7 +12,7 @@ OVC_MAX_LAYERS = 8
 OVC_MAX_LEVELS = 4
 OVC_MAX_BEAM = 8
 OVC_PROFILE_CLASSES = 4
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 _ERRORS = {-1: "OVC_EINVAL (bad argument / unsupported shape)", -2: "OVC_EWORKSPACE (workspace too small)",
            -3: "OVC_ELAUNCH (HIP launch failed)"}
@@ -90,11 +90,16 @@ SIGNATURES = {
     "ovc_encode": (c_int, [POINTER(Model), c_void_p, c_void_p, c_int, c_int, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]),
     "ovc_beam_search": (c_int, [POINTER(Model), c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_size_t,
                                 c_void_p, c_void_p, c_void_p, c_void_p]),
-    "ovc_gemm_tune": (c_int, [c_int, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
+    "ovc_gemm_tune": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
+    "ovc_gemm_tune_calls": (c_long, []),
     "ovc_gemm_tune_objective": (c_int, [c_int]),
-    "ovc_gemm_tuned_get": (c_int, [c_int, c_int, c_int, c_int]),
-    "ovc_gemm_tuned_set": (c_int, [c_int, c_int, c_int, c_int, c_int]),
+    "ovc_gemm_tuned_get": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
+    "ovc_gemm_tuned_set": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
+    "ovc_engine_gemm_shapes": (c_int, [POINTER(Model), c_int, c_int, c_int, POINTER(c_int32), c_int]),
+    "ovc_graph_cache_drop_workspace": (c_int, [c_void_p]),
+    "ovc_graph_cache_size": (c_int, []),
     "ovc_debug_force_gemm_tiling": (c_int, [c_int]),
+    "ovc_debug_linear_tiling": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "ovc_debug_repeat_linear": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "ovc_beam_search_graph": (c_int, [POINTER(Model), c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_size_t,
                                       c_void_p, c_void_p, c_void_p]),

@@ -1,10 +1,15 @@
 """End-to-end parity of the HIP path against reference goldens and the CPU oracle.
 
 Bar (BASELINE.json north_star): token ids bit-exact, log-probabilities within 1e-3 relative.
-Beam search picks by fp32 score comparisons, so an image whose reference decision margin is below
-the fp32 noise of a differently-ordered summation can legitimately flip; ids are asserted exactly
-for every image whose smallest margin exceeds ``MARGIN`` and the fraction of such images is
-required to be large.
+
+Two kinds of comparison:
+
+* engine vs engine (another batch size, another tiling, halves vs whole, graph vs plain launches, padded vs
+  unpadded regions): EXACT equality of ids and log-probabilities.  Every GEMM sums over K in an order fixed per
+  call site (csrc/gemm.hip, K-order classes), so nothing a timing run or a batch size decides can move a bit.
+* engine vs the reference (goldens) / the CPU oracle: another summation order (CPU BLAS), so an image whose
+  reference decision margin is below fp32 noise can legitimately flip; ids are asserted exactly for every image
+  whose smallest margin exceeds ``MARGIN``, and each test prints the decided / identical fractions it saw.
 """
 import numpy as np
 import pytest
@@ -136,8 +141,12 @@ def test_full_size_against_reference_goldens(variant):
                                                      MARGIN, variant + " " + p)
             assert decided.mean() >= 0.75, "{}: fixture has too few decided images".format(p)
             same = (ids.cpu().numpy() == g[p + "ids"]).all(axis=1)
+            print("[parity] {} {}: decided {}/{} images, identical to the reference {}/{} (100 % of decided)"
+                  .format(variant, p, int(decided.sum()), B, int(same.sum()), B))
             _logp_close(logp.cpu().numpy()[same], g[p + "logp"][same], variant + " " + p + "logp")
-            assert same.mean() >= 0.9, "{}: only {:.0%} of images reproduce the reference ids".format(p, same.mean())
+            # The engine's summation orders are fixed, so this outcome is the same on every box and at every batch size:
+            # on these fixtures even the images whose margins are below fp32 noise come out as the reference decoded them.
+            assert same.all(), "{}: images {} differ from the reference ids".format(p, np.nonzero(~same)[0])
 
 
 @pytest.mark.parametrize("variant", VARIANTS)
@@ -158,27 +167,38 @@ def test_full_size_teacher_forced_forward(variant):
                                rtol=1e-3, atol=1e-4)
 
 
-def test_batch_256_properties():
+def _batch_256_properties(variant):
     """Full BASELINE size (B=256, beam 5): size-independent properties.
 
-    Images are independent, so decoding 256 images at once must equal decoding them in two halves
-    and must be reproducible run to run; the first 16 images must reproduce the B=16 golden."""
-    g = golden("g2_full_standard_transformer.npz")
-    cfg, vocab, sd, feats, _ = full_case("standard_transformer", 256)
+    Images are independent, so decoding 256 images at once must equal -- bit for bit, ids and log-probabilities --
+    decoding them in two halves, decoding the first 16 alone, and decoding them again; the first 16 images must
+    reproduce the B=16 reference golden wherever the reference's own decision margins exceed fp32 noise."""
+    g = golden("g2_full_%s.npz" % variant)
+    cfg, vocab, sd, feats, boxes = full_case(variant, 256)
     model = device_model(cfg, vocab, sd)
+    part = lambda lo, hi: batch(feats[lo:hi], None if boxes is None else boxes[lo:hi])
     with torch.no_grad():
-        ids, logp = model.beam_search(batch(feats), batch_size=256, beam_size=5)
-        ids_again, _ = model.beam_search(batch(feats), batch_size=256, beam_size=5)
-        lo, _ = model.beam_search(batch(feats[:128]), batch_size=128, beam_size=5)
-        hi, _ = model.beam_search(batch(feats[128:]), batch_size=128, beam_size=5)
-    assert torch.equal(ids, ids_again)
-    # another batch size means other GEMM tilings, i.e. another fp32 summation order: an image whose beam decision
-    # margin is below that noise (~5e-6) may legitimately differ; none does on this data, a couple are tolerated
-    assert (ids == torch.cat([lo, hi])).all(dim=1).float().mean() >= 0.99
+        ids, logp = model.beam_search(part(0, 256), batch_size=256, beam_size=5)
+        ids_again, logp_again = model.beam_search(part(0, 256), batch_size=256, beam_size=5)
+        lo, lo_lp = model.beam_search(part(0, 128), batch_size=128, beam_size=5)
+        hi, hi_lp = model.beam_search(part(128, 256), batch_size=128, beam_size=5)
+        first, first_lp = model.beam_search(part(0, 16), batch_size=16, beam_size=5)
+    assert torch.equal(ids, ids_again) and torch.equal(logp, logp_again)
+    assert torch.equal(ids, torch.cat([lo, hi])) and torch.equal(logp, torch.cat([lo_lp, hi_lp]))
+    assert torch.equal(ids[:16], first) and torch.equal(logp[:16], first_lp)
     assert ids.min() >= 0 and ids.max() < FULL["V"]
-    same = (ids[:16].cpu().numpy() == g["B16_k5_ids"]).all(axis=1)
-    assert same.mean() >= 0.75
     assert torch.isfinite(logp).all() and (logp <= 0).all()
+    if boxes is None:      # (ORT draws its boxes per batch size: its B=16 golden is checked by the full-size test)
+        p = "B16_k5_"
+        decided = assert_ids_match_where_decided(ids[:16].cpu().numpy(), g[p + "ids"], g[p + "gap"], g[p + "inner_gap"], MARGIN,
+                                                 variant + " first 16 of 256")
+        same = (ids[:16].cpu().numpy() == g[p + "ids"]).all(axis=1)
+        print("[parity] {} B=256[:16] vs reference B=16: decided {}/16, identical {}/16".format(variant, int(decided.sum()), int(same.sum())))
+        assert same.all()          # deterministic summation order: the same outcome on every box (see the full-size test)
+
+
+def test_batch_256_properties():
+    _batch_256_properties("standard_transformer")
 
 
 def test_oracle_agreement_on_ragged_inputs():
@@ -226,22 +246,35 @@ def test_reference_checkpoint_runs_on_the_engine():
 
 @pytest.mark.parametrize("variant", ["meshed_memory_transformer", "object_relation_transformer", "attention_on_attention"])
 def test_batch_256_properties_other_architectures(variant):
-    """BASELINE configs 3 and 4 (and AoA) at the full batch: halves == whole, run-to-run identical,
-    first 16 images == the B=16 reference golden (ORT draws boxes per batch, so it checks B=16 separately)."""
-    g = golden("g2_full_%s.npz" % variant)
-    cfg, vocab, sd, feats, boxes = full_case(variant, 256)
+    """BASELINE configs 3 and 4 (and AoA) at the full batch: halves == whole == first 16 alone, exactly."""
+    _batch_256_properties(variant)
+
+
+def test_results_do_not_depend_on_the_gemm_tiling():
+    """Force, in turn, every tiling of each K-order class on all GEMMs of that class (what different boxes' timing
+    runs would pick at most) and decode the same batch: ids and log-probabilities must not move by one bit."""
+    import re
+    from openviic_amd import native
+    from openviic_amd.engine import CaptionEngine
+    lib = native.load()
+    cfg, vocab, sd, feats, _ = full_case("standard_transformer", 16)
     model = device_model(cfg, vocab, sd)
+    engine = CaptionEngine(model)
+    engine.use_graph = False            # a captured graph would keep the kernels it was captured with
+    x = feats.cuda()
     with torch.no_grad():
-        ids, logp = model.beam_search(batch(feats, boxes), batch_size=256, beam_size=5)
-        again, _ = model.beam_search(batch(feats, boxes), batch_size=256, beam_size=5)
-        lo, _ = model.beam_search(batch(feats[:128], None if boxes is None else boxes[:128]), batch_size=128, beam_size=5)
-        hi, _ = model.beam_search(batch(feats[128:], None if boxes is None else boxes[128:]), batch_size=128, beam_size=5)
-    assert torch.equal(ids, again)
-    assert (ids == torch.cat([lo, hi])).all(dim=1).float().mean() >= 0.99      # see test_batch_256_properties
-    assert torch.isfinite(logp).all() and ids.min() >= 0 and ids.max() < FULL["V"]
-    if boxes is None:
-        same = (ids[:16].cpu().numpy() == g["B16_k5_ids"]).all(axis=1)
-        assert same.mean() >= 0.9
+        want_ids, want_lp = engine.beam_search(x, None, 16, 5)
+    t = 0
+    try:
+        while lib.ovc_profile_kernel_name(t):
+            assert lib.ovc_debug_force_gemm_tiling(t) == 0
+            with torch.no_grad():
+                ids, lp = engine.beam_search(x, None, 16, 5)
+            assert torch.equal(ids, want_ids) and torch.equal(lp, want_lp), lib.ovc_profile_kernel_name(t).decode()
+            t += 1
+    finally:
+        lib.ovc_debug_force_gemm_tiling(-1)
+    assert t == 15
 
 
 def test_hipgraph_replay_matches_plain_launches():
@@ -333,31 +366,93 @@ def test_invalid_requests_fail_loudly():
     assert ids.shape == (feats.shape[0], TINY_SHAPE["T"])
 
 
-@pytest.mark.parametrize("split", [2, 4])
-def test_k_split_projections_against_reference_golden(split):
-    """The projections back to d_model (self / cross output, second FFN layer) run as K-split GEMMs whose partial
-    products the LayerNorm kernel sums, where the tuner measures that as faster.  Here the choice is preset for
-    the B=16, beam-5 shapes so that the path is exercised whatever the tuner would pick on this device."""
+def test_varying_region_counts_never_retune_and_match_the_exact_shapes():
+    """Real-data batches are padded to the batch's largest region count (utils/instance.py:156-171), so N changes from
+    batch to batch.  After the first batch no tiling measurement may run (neighbouring shapes borrow the entry), the
+    graph cache stays bounded, and -- with region bucketing on -- the zero-padded decode returns exactly what the
+    unpadded one does."""
     from openviic_amd import native
+    from openviic_amd.engine import CaptionEngine
     lib = native.load()
-    g = golden("g2_full_standard_transformer.npz")
-    B, k = 16, 5
-    cfg, vocab, sd, feats, _ = full_case("standard_transformer", B)
-    for rows in (B, B * k):
-        for K in (512, 2048):
-            code = 3 | split << 8 | 3 << 16                    # plain: 64x64; split: `split` slices of 64x64 tiles
-            assert lib.ovc_gemm_tuned_set(rows, 512, 1, K, code) == 0
-            assert lib.ovc_gemm_tuned_get(rows, 512, 1, K) == code
+    cfg, vocab, sd, feats, _ = full_case("standard_transformer", 8)
+    model = device_model(cfg, vocab, sd)
+    exact = CaptionEngine(model)
+    bucketed = CaptionEngine(model)
+    bucketed.region_bucket = 16
+    orc = OracleCaptioner(cfg, sd, len(vocab), vocab.max_caption_length)
+    stream = torch.cuda.Stream()
+    calls = None
+    for n in (37, 50, 44, 50, 37):
+        x = feats[:, :n].contiguous().cuda()
+        with torch.no_grad(), torch.cuda.stream(stream):
+            a_ids, a_lp = exact.beam_search(x, None, 8, 5)
+            b_ids, b_lp = bucketed.beam_search(x, None, 8, 5)
+        stream.synchronize()
+        assert torch.equal(a_ids, b_ids) and torch.equal(a_lp, b_lp), n          # zero rows are exact padding
+        if calls is None:
+            calls = lib.ovc_gemm_tune_calls()                                    # the first batch may measure
+        assert lib.ovc_gemm_tune_calls() == calls, "a tiling measurement ran for N = %d" % n
+        rec = {}
+        want_ids, _ = orc.beam_search(feats[:, :n].contiguous(), 5, record=rec)
+        assert_ids_match_where_decided(a_ids.cpu().numpy(), want_ids.numpy(), torch.stack(rec["gap"]).numpy(),
+                                       torch.stack(rec["inner_gap"]).numpy(), MARGIN, "N=%d" % n)
+    assert 0 < lib.ovc_graph_cache_size() <= 24
+    held = lib.ovc_graph_cache_size()
+    exact.release()                       # dropping an engine's workspaces drops the graphs captured on them
+    bucketed.release()
+    assert lib.ovc_graph_cache_size() < held
+
+
+def test_in_place_weight_updates_reach_the_engine():
+    """The engine references parameters by pointer; the one derived copy (the geometric encoder's stacked fc_gs) must
+    follow ``load_state_dict`` / optimizer-style in-place updates made between two beam_search calls."""
+    cfg, vocab, sd, feats, boxes = tiny_case("object_relation_transformer")
     model = device_model(cfg, vocab, sd)
     with torch.no_grad():
-        ids, logp = model.beam_search(batch(feats), batch_size=B, beam_size=k)
-    p = "B16_k5_"
-    assert_ids_match_where_decided(ids.cpu().numpy(), g[p + "ids"], g[p + "gap"], g[p + "inner_gap"], MARGIN, "k-split")
-    same = (ids.cpu().numpy() == g[p + "ids"]).all(axis=1)
-    assert same.mean() >= 0.9
-    _logp_close(logp.cpu().numpy()[same], g[p + "logp"][same], "k-split logp")
-    assert lib.ovc_gemm_tuned_set(16, 512, 1, 2048, 3 | 8 << 8 | 3 << 16) != 0      # more than 4 slices: refused
-    assert lib.ovc_gemm_tuned_set(16, 512, 3, 2048, 3 | 2 << 8 | 3 << 16) != 0      # segmented outputs cannot split
+        before, _ = model.beam_search(batch(feats, boxes), batch_size=feats.shape[0], beam_size=3)
+        sd2 = {k: v.clone() for k, v in sd.items()}
+        g = torch.Generator().manual_seed(99)
+        for k in sd2:
+            if ".fc_gs." in k or "fc_q.weight" in k:
+                sd2[k] = sd2[k] + 0.5 * torch.randn(sd2[k].shape, generator=g)
+        model.load_state_dict(sd2, strict=False)               # in place: same storage, same engine
+        after, after_lp = model.beam_search(batch(feats, boxes), batch_size=feats.shape[0], beam_size=3)
+    fresh = device_model(cfg, vocab, sd2)
+    with torch.no_grad():
+        want, want_lp = fresh.beam_search(batch(feats, boxes), batch_size=feats.shape[0], beam_size=3)
+    assert torch.equal(after, want) and torch.equal(after_lp, want_lp)
+    assert not torch.equal(before, after)
+
+
+def test_two_host_threads_decode_concurrently():
+    """One stream per host thread; ctypes releases the GIL during the calls, so tuning look-ups, graph capture and
+    launches of the two threads interleave inside the library."""
+    import threading
+    cfg, vocab, sd, feats, _ = full_case("standard_transformer", 16)
+    model = device_model(cfg, vocab, sd)
+    halves = [feats[:8].cuda(), feats[8:].cuda()]
+    with torch.no_grad():
+        want = [model.beam_search(batch(h), batch_size=8, beam_size=5) for h in halves]
+    torch.cuda.synchronize()
+    got, errors = [None, None], []
+
+    def work(i):
+        try:
+            s = torch.cuda.Stream()
+            with torch.no_grad(), torch.cuda.stream(s):
+                for _ in range(4):
+                    got[i] = model.beam_search(batch(halves[i]), batch_size=8, beam_size=5)
+            s.synchronize()
+        except Exception as exc:            # pragma: no cover
+            errors.append(exc)
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors
+    for (ids, lp), (wi, wl) in zip(got, want):
+        assert torch.equal(ids, wi) and torch.equal(lp, wl)
 
 
 DIMS = [
@@ -369,13 +464,15 @@ DIMS = [
     ("meshed_memory_transformer", dict(d_feature=48, d_model=128, heads=2, d_kv=64, d_ff=256, layers=4, memory=7), (2, 20, 211, 6, 3)),  # 4 levels
     ("object_relation_transformer", dict(d_feature=32, d_model=192, heads=3, d_kv=64, d_ff=384, layers=2), (2, 33, 150, 6, 3)),          # 3 heads
     ("attention_on_attention", dict(d_feature=32, d_model=128, heads=4, d_kv=32, d_ff=256, layers=2), (3, 17, 131, 7, 5)),
+    ("standard_transformer", dict(d_feature=24, d_model=64, heads=8, d_kv=8, d_ff=128, layers=2), (3, 11, 120, 6, 3)),      # d_k = 8: the LDS cross-attention kernel
+    ("meshed_memory_transformer", dict(d_feature=24, d_model=64, heads=16, d_kv=4, d_ff=64, layers=2, memory=3), (2, 6, 61, 5, 2)),   # d_k = 4, 16 heads
 ]
 
 
 @pytest.mark.parametrize("variant,dims,shape", DIMS, ids=[d[0] + "-" + "x".join(map(str, d[2])) for d in DIMS])
 def test_unusual_dimensions_against_oracle(variant, dims, shape):
     """Architecture sizes away from the BASELINE ones, each at a limit of the engine or of a kernel instance (N = 128 regions, V = 16384 and 30011
-    words, max_len = 64, 8 layers, 4 meshed levels, d_k in {16, 32, 64}, head counts that are not powers of two)."""
+    words, max_len = 64, 8 layers, 4 meshed levels, d_k in {4, 8, 16, 32, 64}, head counts that are not powers of two)."""
     from openviic_amd.config import model_config
     from openviic_amd.utils.synthetic import SyntheticVocab, synthetic_boxes, synthetic_features, synthetic_state_dict
     from openviic_amd.builders import build_model
@@ -437,5 +534,5 @@ def test_image_without_regions_is_harmless():
         got, got_lp = model.beam_search(batch(padded), batch_size=padded.shape[0], beam_size=3)
         again, _ = model.beam_search(batch(feats), batch_size=feats.shape[0], beam_size=3)      # the engine is still usable
     assert torch.equal(got[:-1], want) and torch.equal(again, want)
-    _logp_close(got_lp[:-1].cpu().numpy(), want_lp.cpu().numpy(), "other images next to an image without regions")   # other batch size, other tilings
+    assert torch.equal(got_lp[:-1], want_lp)              # another batch size changes tilings, never bits
     assert got[-1].min() >= 0 and got[-1].max() < TINY_SHAPE["V"]

@@ -366,26 +366,110 @@ def test_beam_select_random_shapes():
             np.testing.assert_array_equal(masked.cpu().numpy(), want_masked.numpy(), err_msg=what)
 
 
-@pytest.mark.parametrize("M,N,K", [(130, 200, 96), (65, 33, 36), (1280, 512, 512), (257, 1536, 128), (31, 10201, 64)])
-def test_linear_every_tiling(M, N, K):
-    """Every instance of the GEMM template on shapes with M / N tails and (K = 36) a K tail, bias + ReLU + residual
-    epilogue, against fp64; the forced-tiling hook is the one tools/gemm_bench.py uses."""
-    from openviic_amd import native, ops
+def _tilings(lib):
+    """[(index, kernel name, chains of its K-order class)] of every instance of the GEMM template."""
+    import re
+    out = []
+    t = 0
+    while lib.ovc_profile_kernel_name(t):
+        name = lib.ovc_profile_kernel_name(t).decode()
+        wk, nc = (int(v) for v in re.match(r"gemm_f32_mfma<\d+, \d+, \d+, \d+, (\d+), \d+, (\d+)>", name).groups())
+        out.append((t, name, wk * nc))
+        t += 1
+    return out
+
+
+def _linear_by_tiling(lib, native, xd, wd, bd, tiling, ksplit=1):
+    M, K = xd.shape
+    N = wd.shape[0]
+    y = torch.empty((ksplit, M, N) if ksplit > 1 else (M, N), device=DEV)
+    rc = lib.ovc_debug_linear_tiling(xd.data_ptr(), K, wd.data_ptr(), None if bd is None else bd.data_ptr(), y.data_ptr(),
+                                     M, N, tiling, ksplit, native.stream_handle())
+    return rc, y
+
+
+@pytest.mark.parametrize("M,N,K", [(130, 200, 96), (65, 33, 36), (1280, 512, 512), (257, 1536, 128), (31, 10201, 64),
+                                   (640, 512, 2048), (5, 64, 32)])
+def test_every_tiling_of_a_k_order_class_gives_the_same_bits(M, N, K):
+    """The order in which a product sums over K is fixed per K-order class (gemm.hip): one chain, or four interleaved
+    chains summed ((c0+c1)+c2)+c3 whether the chains live in one wave, two or four.  So every instance of the GEMM
+    template must agree with fp64 within tolerance AND bit for bit with every other instance of its class -- which
+    tiling a timing run picks can then never change a token id.  Shapes with M / N tails and (K = 36) a K tail."""
+    from openviic_amd import native
     lib = native.load()
+    lib.ovc_profile_kernel_name.restype = __import__("ctypes").c_char_p
     g = torch.Generator().manual_seed(M + N + K)
     x, w = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) / math.sqrt(K)
-    b, r = torch.randn(N, generator=g), torch.randn(M, N, generator=g)
-    want = torch.relu(x.double() @ w.double().T + b.double()) + r.double()
-    xd, wd, bd, rd = (t.to(DEV) for t in (x, w, b, r))
-    try:
-        t = 0
-        while lib.ovc_debug_force_gemm_tiling(t) == 0:
-            got = ops.linear(xd, wd, bd, relu=True, residual=rd)
-            _close(got, want, what="tiling %d on %dx%dx%d" % (t, M, N, K))
-            t += 1
-        assert t == 12
-    finally:
-        lib.ovc_debug_force_gemm_tiling(-1)
+    b = torch.randn(N, generator=g)
+    want = x.double() @ w.double().T + b.double()
+    xd, wd, bd = (t.to(DEV) for t in (x, w, b))
+    tilings = _tilings(lib)
+    assert len(tilings) == 15 and {c for _, _, c in tilings} == {1, 4}
+    first = {}
+    for t, name, chains in tilings:
+        rc, got = _linear_by_tiling(lib, native, xd, wd, bd, t)
+        assert rc == 0, name
+        _close(got, want, what="%s on %dx%dx%d" % (name, M, N, K))
+        if chains in first:
+            assert torch.equal(got, first[chains][1]), "%s differs from %s (same K-order class)" % (name, first[chains][0])
+        else:
+            first[chains] = (name, got)
+    if K >= 256:      # one chain and four chains are different summation orders: the classes are not interchangeable
+        assert not torch.equal(first[1][1], first[4][1])
+
+
+@pytest.mark.parametrize("ksplit", [2, 4])
+def test_k_slices_are_bit_identical_across_tilings_and_sum_to_the_product(ksplit):
+    """K-split products (engine: the decode-step projections back to d_model): slice s is the product over
+    k in [s K/ksplit, (s+1) K/ksplit); every tiling of the class writes the same partial products."""
+    from openviic_amd import native
+    lib = native.load()
+    lib.ovc_profile_kernel_name.restype = __import__("ctypes").c_char_p
+    M, N, K = 333, 512, 1024
+    g = torch.Generator().manual_seed(ksplit)
+    x, w = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) / math.sqrt(K)
+    xd, wd = x.to(DEV), w.to(DEV)
+    first = {}
+    for t, name, chains in _tilings(lib):
+        rc, parts = _linear_by_tiling(lib, native, xd, wd, None, t, ksplit)
+        if rc != 0:           # a slice must be a whole number of this tiling's K tiles
+            continue
+        ks = K // ksplit
+        for s_ in range(ksplit):
+            _close(parts[s_], x[:, s_ * ks:(s_ + 1) * ks].double() @ w[:, s_ * ks:(s_ + 1) * ks].double().T, what="%s slice %d" % (name, s_))
+        if chains in first:
+            assert torch.equal(parts, first[chains])
+        else:
+            first[chains] = parts
+    assert set(first) == {1, 4}
+
+
+def test_tuner_only_ranks_inside_the_class_and_borrows_neighbouring_shapes():
+    from openviic_amd import native
+    lib = native.load()
+    M, N, K = 192, 256, 128
+    scratch = torch.randn(4 * (M * K + N * K + 4 * M * N) // 4 + 64, device=DEV)
+    for chains in (1, 4):
+        assert lib.ovc_gemm_tuned_get(M, N, 1, K, chains, 1, 0) == -1
+        calls = lib.ovc_gemm_tune_calls()
+        assert lib.ovc_gemm_tune(M, N, 1, K, chains, 1, scratch.data_ptr(), scratch.numel() * 4, native.stream_handle()) == 0
+        assert lib.ovc_gemm_tune_calls() == calls + 1
+        t = lib.ovc_gemm_tuned_get(M, N, 1, K, chains, 1, 0)
+        assert t >= 0 and dict((i, c) for i, _, c in _tilings_cached(lib))[t] == chains
+        assert lib.ovc_gemm_tune(M, N, 1, K, chains, 1, scratch.data_ptr(), scratch.numel() * 4, native.stream_handle()) == 0
+        assert lib.ovc_gemm_tune_calls() == calls + 1                       # already measured: nothing runs
+        assert lib.ovc_gemm_tuned_get(M + 40, N, 1, K, chains, 1, 0) == -1     # exact look-up misses ...
+        assert lib.ovc_gemm_tuned_get(M + 40, N, 1, K, chains, 1, 1) == t      # ... the near one borrows the neighbour
+        assert lib.ovc_gemm_tuned_get(4 * M, N, 1, K, chains, 1, 1) == -1      # but not across more than a factor of two
+        wrong = next(i for i, _, c in _tilings_cached(lib) if c != chains)
+        assert lib.ovc_gemm_tuned_set(M, N, 1, K, chains, 1, wrong) != 0       # a tiling of the other class is refused
+    assert lib.ovc_gemm_tuned_set(16, 512, 3, 2048, 4, 2, 7) != 0              # segmented outputs cannot split
+    assert lib.ovc_gemm_tuned_set(16, 512, 1, 2048, 4, 8, 7) != 0              # more than 4 slices
+
+
+def _tilings_cached(lib):
+    lib.ovc_profile_kernel_name.restype = __import__("ctypes").c_char_p
+    return _tilings(lib)
 
 
 def test_beam_select_with_nan_scores_returns_in_range_indices():
