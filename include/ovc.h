@@ -266,10 +266,11 @@ int ovc_graph_cache_size(void);
 /* Debug / measurement hooks (tools/, tests/).  ovc_debug_force_gemm_tiling: every following GEMM of the forced
  * tiling's class uses it (-1 restores the automatic choice); process-wide, not for use while other threads decode.
  * ovc_debug_linear_tiling: y = x W^T + bias by ONE named tiling (its class follows from the tiling; the name is
- * ovc_profile_kernel_name(tiling)); with ksplit > 1, y receives the ksplit raw partial products [ksplit][M][N]. */
+ * ovc_profile_kernel_name(tiling)); with ksplit > 1, y receives the ksplit raw partial products [ksplit][M][N];
+ * `iters` back-to-back launches. */
 int ovc_debug_force_gemm_tiling(int tiling);
 int ovc_debug_linear_tiling(const float* x, int K, const float* W, const float* bias, float* y, int M, int N,
-                            int tiling, int ksplit, ovc_stream stream);
+                            int tiling, int ksplit, int iters, ovc_stream stream);
 /* `iters` back-to-back launches of y = x W^T + bias (x [M,K], W [N,K]) with no host work between. */
 int ovc_debug_repeat_linear(const float* x, int K, const float* W, const float* bias, float* y,
                             int M, int N, int iters, ovc_stream stream);

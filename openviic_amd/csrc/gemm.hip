@@ -84,8 +84,13 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return base + (bid >> 3);
 }
 
+// Registers are capped where residency matters: the M = 1280 decode products come as 1280 workgroups of 32x64 tiles,
+// five per CU -- with more than 96 registers only four are resident and the fifth runs as a second round (35 vs 28 us).
+template <int BM, int BN, int BK, int NC>
+constexpr int min_waves_per_simd() { return BM * BN <= 32 * 64 ? 5 : (BM * BN <= 64 * 64 ? (NC == 4 && BK == 64 ? 3 : 4) : 1); }
+
 template <int BM, int BN, int WM, int WN, int WK, int BK, int NC>
-__global__ __launch_bounds__(256) void gemm_f32_mfma(GemmArgs p, int tiles_m, int tiles_n_per_seg, int group_m, int xcd_pm) {
+__global__ __launch_bounds__(256, (min_waves_per_simd<BM, BN, BK, NC>())) void gemm_f32_mfma(GemmArgs p, int tiles_m, int tiles_n_per_seg, int group_m, int xcd_pm) {
     using Cfg = TileConfig<BM, BN, WM, WN, WK, BK, NC>;
     constexpr int LDT = Cfg::LDT;
     constexpr int kVecPerRow = BK / 4;               // float4 per tile row
@@ -637,15 +642,19 @@ extern "C" int ovc_debug_repeat_linear(const float* x, int K, const float* W, co
 // show that all tilings of a class give the same bits.  ksplit > 1: y receives `ksplit` raw partial products
 // [ksplit][M][N] (no bias).
 extern "C" int ovc_debug_linear_tiling(const float* x, int K, const float* W, const float* bias, float* y, int M, int N,
-                                       int tiling, int ksplit, ovc_stream stream) {
-    if (tiling < 0 || tiling >= kNumTilings || !x || !W || !y) return OVC_EINVAL;
+                                       int tiling, int ksplit, int iters, ovc_stream stream) {
+    if (tiling < 0 || tiling >= kNumTilings || !x || !W || !y || iters < 1) return OVC_EINVAL;
     GemmArgs a{};
     a.A1 = x; a.lda1 = K; a.K1 = K; a.M = M; a.seg_n = N; a.nseg = 1; a.ldc = N; a.kchains = tiling_chains(tiling);
     a.seg[0] = GemmSegment{W, ksplit > 1 ? nullptr : bias, y, nullptr};
     if (ksplit > 1) { a.ksplit = ksplit; a.part_stride = (long)M * N; }
     GemmLaunchOpts opts{};
     opts.forced_tiling = tiling;
-    return ovc_gemm_launch(a, ovc_hip_stream(stream), opts);
+    for (int i = 0; i < iters; ++i) {                    // back to back, no host work in between (tools/gemm_bench.py)
+        const int rc = ovc_gemm_launch(a, ovc_hip_stream(stream), opts);
+        if (rc != OVC_OK) return rc;
+    }
+    return OVC_OK;
 }
 
 extern "C" int ovc_linear(const float* x, int ldx, const float* x2, int ldx2, int K1, int K2,

@@ -99,7 +99,7 @@ SIGNATURES = {
     "ovc_graph_cache_drop_workspace": (c_int, [c_void_p]),
     "ovc_graph_cache_size": (c_int, []),
     "ovc_debug_force_gemm_tiling": (c_int, [c_int]),
-    "ovc_debug_linear_tiling": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "ovc_debug_linear_tiling": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "ovc_debug_repeat_linear": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "ovc_beam_search_graph": (c_int, [POINTER(Model), c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_size_t,
                                       c_void_p, c_void_p, c_void_p]),

@@ -384,7 +384,7 @@ def _linear_by_tiling(lib, native, xd, wd, bd, tiling, ksplit=1):
     N = wd.shape[0]
     y = torch.empty((ksplit, M, N) if ksplit > 1 else (M, N), device=DEV)
     rc = lib.ovc_debug_linear_tiling(xd.data_ptr(), K, wd.data_ptr(), None if bd is None else bd.data_ptr(), y.data_ptr(),
-                                     M, N, tiling, ksplit, native.stream_handle())
+                                     M, N, tiling, ksplit, 1, native.stream_handle())
     return rc, y
 
 

@@ -1,76 +1,82 @@
 #!/usr/bin/env python3
 """Micro-benchmark of the fp32 MFMA GEMM on the shapes of the captioning path (runs on the GPU box).
 
-For every shape: time of each tiling (forced through ovc_debug_force_gemm_tiling), of the automatic
-choice, and of torch.mm (rocBLAS / hipBLASLt) as a same-hardware reference.  Random operands.
+For every (shape, K-order class, K split) the engine issues: time of each tiling of that class
+(ovc_debug_linear_tiling, back-to-back launches issued from C) and of torch.addmm (rocBLAS / hipBLASLt) as a
+same-hardware reference.  Random operands.   python tools/gemm_bench.py [decode|encoder|all]
 """
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from openviic_amd import native, ops
+from openviic_amd import native
 
-SHAPES = [  # (M, N, K, note)
-    (1280, 512, 512, "dec o/q proj"), (1280, 1536, 512, "dec qkv (3 seg)"), (1280, 2048, 512, "dec ffn1"),
-    (1280, 512, 2048, "dec ffn2"), (1280, 10201, 512, "vocab"), (256, 512, 512, "t=0 proj"),
-    (256, 10201, 512, "t=0 vocab"), (12800, 512, 2048, "feature proj"), (12800, 1536, 512, "enc qkv"),
-    (12800, 512, 512, "enc o"), (12800, 2048, 512, "enc ffn1"), (12800, 512, 2048, "enc ffn2"),
-    (12800, 3072, 512, "cross kv (6 seg)"),
+DECODE = [  # (M, N, K, kchains, ksplit, note)
+    (1280, 512, 512, 4, 1, "dec cross-q"), (1280, 512, 512, 4, 2, "dec o-proj /2"), (1280, 1536, 512, 4, 1, "dec qkv"),
+    (1280, 2048, 512, 4, 1, "dec ffn1"), (1280, 512, 2048, 4, 4, "dec ffn2 /4"), (1280, 512, 2048, 4, 2, "dec ffn2 /2"),
+    (1280, 10201, 512, 4, 1, "vocab"), (256, 512, 512, 4, 1, "t=0 proj"), (256, 10201, 512, 4, 1, "t=0 vocab"),
 ]
-TILINGS = ["128x128", "64x128", "128x64", "64x64", "32x64k2", "64x32k2", "32x32k4", "64x64b64", "32x64k2b", "64x32k2b", "32x32k4b", "64x128b"]
+ENCODER = [
+    (12800, 512, 2048, 1, 1, "feature proj"), (12800, 1536, 512, 1, 1, "enc qkv"), (12800, 512, 512, 1, 1, "enc o"),
+    (12800, 2048, 512, 1, 1, "enc ffn1"), (12800, 3072, 512, 1, 1, "cross kv"),
+]
 
 
-def timeit(fn, iters=30):
-    for _ in range(5):
-        fn()
-    torch.cuda.synchronize()
-    start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    start.record()
-    for _ in range(iters):
-        fn()
-    stop.record()
-    torch.cuda.synchronize()
-    return start.elapsed_time(stop) / iters * 1e3       # microseconds
+def tilings(lib):
+    out, t = [], 0
+    while lib.ovc_profile_kernel_name(t):
+        name = lib.ovc_profile_kernel_name(t).decode()
+        v = [int(x) for x in name[name.index("<") + 1:-1].split(",")]
+        out.append((t, "%dx%d w%d b%d c%d" % (v[0], v[1], v[4], v[5], v[6]), v[4] * v[6]))
+        t += 1
+    return out
 
 
-def time_native(lib, x, w, b, y, iters=50):
-    """Back-to-back launches issued from C: no Python between kernels (host launch rate still applies)."""
+def time_tiling(lib, x, w, b, y, t, ksplit, iters=40):
     M, K = x.shape
     N = w.shape[0]
-    args = (x.data_ptr(), K, w.data_ptr(), b.data_ptr(), y.data_ptr(), M, N)
-    lib.ovc_debug_repeat_linear(*args, 5, native.stream_handle())
+    args = (x.data_ptr(), K, w.data_ptr(), b.data_ptr(), y.data_ptr(), M, N, t, ksplit)
+    if lib.ovc_debug_linear_tiling(*args, 5, native.stream_handle()) != 0:
+        return None
     torch.cuda.synchronize()
     start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     start.record()
-    lib.ovc_debug_repeat_linear(*args, iters, native.stream_handle())
+    lib.ovc_debug_linear_tiling(*args, iters, native.stream_handle())
     stop.record()
     torch.cuda.synchronize()
     return start.elapsed_time(stop) / iters * 1e3
 
 
 def main():
+    which = sys.argv[1] if len(sys.argv) > 1 else "all"
     lib = native.load()
-    dev = "cuda"
-    print("%-22s %8s | %s | %8s %8s | TF(auto) TF(best) ideal_us" % ("shape", "note", " ".join("%8s" % t for t in TILINGS), "auto", "torch"))
-    for M, N, K, note in SHAPES:
-        x = torch.randn(M, K, device=dev)
-        w = torch.randn(N, K, device=dev) / K ** 0.5
-        b = torch.randn(N, device=dev)
-        times = []
-        y = torch.empty(M, N, device=dev)
-        ref_y = torch.addmm(b, x, w.t())
-        for t in range(len(TILINGS)):
-            lib.ovc_debug_force_gemm_tiling(t)
-            times.append(time_native(lib, x, w, b, y))
-            err = (y - ref_y).abs().max().item()
-            if err > 2e-3:
-                print("  !! tiling %s differs from torch.addmm by %.3e" % (TILINGS[t], err))
-        lib.ovc_debug_force_gemm_tiling(-1)
-        auto = time_native(lib, x, w, b, y)
-        ref = timeit(lambda: torch.addmm(b, x, w.t()))
+    shapes = (DECODE if which in ("decode", "all") else []) + (ENCODER if which in ("encoder", "all") else [])
+    tl = tilings(lib)
+    for M, N, K, chains, ksplit, note in shapes:
+        x = torch.randn(M, K, device="cuda")
+        w = torch.randn(N, K, device="cuda") / K ** 0.5
+        b = torch.randn(N, device="cuda")
+        y = torch.empty(max(ksplit, 1), M, N, device="cuda")
+        for _ in range(5):
+            torch.addmm(b, x, w.t())
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(30):
+            torch.addmm(b, x, w.t())
+        e1.record()
+        torch.cuda.synchronize()
+        ref = e0.elapsed_time(e1) / 30 * 1e3
         flops = 2.0 * M * N * K
-        print("%-22s %8s | %s | %8.1f %8.1f | %7.1f %7.1f %7.1f" % (
-            "%dx%dx%d" % (M, N, K), note[:8], " ".join("%8.1f" % t for t in times), auto, ref,
-            flops / auto / 1e6, flops / min(times) / 1e6, flops / 157.3e6))
+        cells = []
+        for t, label, c in tl:
+            if c != chains:
+                continue
+            us = time_tiling(lib, x, w, b, y, t, ksplit)
+            cells.append((us if us is not None else 1e9, label))
+        cells.sort()
+        print("%-16s %5dx%5dx%4d c%d /%d | torch %6.1f us | ideal %5.1f | %s" % (
+            note, M, N, K, chains, ksplit, ref, flops / 157.3e6,
+            "  ".join("%s: %.1f (%.0f TF)" % (l, u, flops / u / 1e6) for u, l in cells if u < 1e8)), flush=True)
 
 
 if __name__ == "__main__":
