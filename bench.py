@@ -10,10 +10,17 @@ already resident in HBM -> encoder -> 20 beam-search steps (beam 5, V=10201) -> 
 rank decodes its own B images (weak scaling), no data-path collective.  Rank 0 prints ONE JSON
 line; ``value`` is whole-job captions/s (all ranks' images / max-over-ranks time).
 
-``roofline`` covers the dominant kernel, the fp32 MFMA GEMM (every projection / FFN / vocabulary
-product): algorithmic FLOPs 2*M*N*K per launch over its hipEvent-bracketed duration on the launch
-stream, measured in an extra instrumented pass after the timed region.  ``cpu_baseline`` times the
-CPU oracle (which reproduces the reference's operation sequence) on a bounded sample.
+The images go through ``openviic_amd.distributed.decode_sharded`` -- the code the world-size-2 gloo tests
+cover -- at every N: each rank decodes rows ``shard_bounds(B*N, rank, N)`` of the global batch.
+
+Timed region (``value``, ``ms_per_step``): consecutive batches alternate over ``--streams`` HIP streams, decode launch
+sequences replayed as hipGraphs.  ``roofline`` covers the dominant kernel, the fp32 MFMA GEMM (every projection / FFN /
+vocabulary product): algorithmic FLOPs 2*M*N*K per launch over the launch's own duration (kernel-scoped HIP events:
+dispatch begin / end on the launch stream).  Durations of kernels that overlap on different streams do not add up to
+wall time, so that leg runs on ONE stream, right after a timed single-stream region whose ``ms_per_step`` is reported
+next to it (``roofline.single_stream``); ``roofline.timed_mode`` relates the same GEMM FLOPs to the headline wall time.
+``cpu_baseline`` times the CPU oracle (which reproduces the reference's operation sequence): B = 256, one warm-up and
+three timed repeats.
 """
 import argparse
 import json
@@ -59,17 +66,20 @@ def parse():
                     help="HIP streams that consecutive (independent) batches alternate on; decode steps are "
                          "small launches, so several batches in flight fill the chip better than one")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=128, help="images in the CPU-oracle sample (about 13 s on 16 cores)")
+    ap.add_argument("--cpu-sample", type=int, default=256, help="images per CPU-oracle repeat (BASELINE.md: B=256; ~12 s each on 16 cores)")
+    ap.add_argument("--cpu-repeats", type=int, default=3)
     return ap.parse_args()
 
 
-def profiled_gemm_traffic():
-    """HBM bytes per GEMM launch from the committed PMC passes (profiles/*_per_kernel_shape.csv, produced by
-    tools/profile_round.sh: separate FETCH_SIZE / WRITE_SIZE runs, FETCH_SIZE doubled as the gfx950 guide
+def profiled_gemm_traffic(variant):
+    """HBM bytes per GEMM launch from the committed PMC passes of this workload (profiles/*_per_kernel_shape.csv,
+    produced by tools/profile_round.sh: separate FETCH_SIZE / WRITE_SIZE runs, FETCH_SIZE doubled as the gfx950 guide
     prescribes), launch-weighted over the GEMM rows.  Not a live measurement: None when the file is absent."""
     import csv
     import glob
-    files = sorted(glob.glob(os.path.join(REPO, "profiles", "*_per_kernel_shape.csv")))
+    suffix = "" if variant.startswith("standard") else "_" + variant
+    files = sorted(f for f in glob.glob(os.path.join(REPO, "profiles", "r[0-9][0-9]*%s_per_kernel_shape.csv" % suffix))
+                   if suffix or not any(v in os.path.basename(f) for v in ("meshed", "object_relation", "attention_on")))
     if not files:
         return None, None
     launches = total = 0.0
@@ -111,27 +121,42 @@ def usable_cores():
     return max(1, min(cores, 32))
 
 
-def cpu_baseline(cfg, sd, variant, beam, sample):
-    """Oracle (kind "port": reference op sequence restated on PyTorch-CPU) on the host cores."""
+def cpu_model_string():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.lower().startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    import platform
+    return platform.processor() or platform.machine()
+
+
+def cpu_baseline(cfg, sd, variant, beam, sample, repeats):
+    """Oracle (kind "port": reference op sequence restated on PyTorch-CPU) on the host cores, BASELINE.md section 3:
+    same weights and inputs as the GPU run, B = ``sample`` images per call, 1 warm-up + ``repeats`` timed calls, median."""
     from oracle.captioner import OracleCaptioner        # checker / baseline only, never the product path
     cores = usable_cores()
     torch.set_num_threads(cores)
-    print("[bench] cpu baseline: %d images on %d threads (host reports %d cpus)" % (sample, cores, os.cpu_count() or 0),
-          file=sys.stderr, flush=True)
+    cpu = cpu_model_string()
+    print("[bench] cpu baseline: %d images x (1 + %d) calls on %d threads of %s (host reports %d cpus)"
+          % (sample, repeats, cores, cpu, os.cpu_count() or 0), file=sys.stderr, flush=True)
     oracle = OracleCaptioner(cfg, sd, V, T)
     feats = synthetic_features(sample, N_REGIONS, D_FEAT, seed=0)
     boxes = synthetic_boxes(sample, N_REGIONS, seed=0) if variant == "object_relation_transformer" else None
-    oracle.beam_search(feats[:4], beam, boxes=None if boxes is None else boxes[:4])       # warm-up
     times = []
-    for _ in range(2):
+    for rep in range(repeats + 1):
         t0 = time.perf_counter()
         oracle.beam_search(feats, beam, boxes=boxes)
-        times.append(time.perf_counter() - t0)
-        print("[bench] cpu baseline repeat: %.2f s" % times[-1], file=sys.stderr, flush=True)
+        dt = time.perf_counter() - t0
+        print("[bench] cpu baseline %s: %.2f s" % ("warm-up" if rep == 0 else "repeat %d" % rep, dt), file=sys.stderr, flush=True)
+        if rep:
+            times.append(dt)
     return {"value": round(sample / statistics.median(times), 3), "unit": "captions/s", "cores": cores,
-            "kind": "port",
-            "sample": "%d images, beam %d, same weights/inputs, 1 warm-up + 2 timed repeats (median), "
-                      "torch %s CPU fp32, %d threads" % (sample, beam, torch.__version__, cores)}
+            "kind": "port", "cpu": cpu,
+            "sample": "B=%d images per call, beam %d, same weights/inputs as the GPU run, 1 warm-up + %d timed calls "
+                      "(median; min %.2f s, max %.2f s), torch %s CPU fp32, %d threads"
+                      % (sample, beam, repeats, min(times), max(times), torch.__version__, cores)}
 
 
 def main():
@@ -159,32 +184,30 @@ def main():
     sd = synthetic_state_dict(model.state_dict(), seed=1234, mode="reference_init")
     model.load_state_dict(sd, strict=False)
 
-    # every rank draws the same global batch and takes its contiguous shard
-    feats = synthetic_features(B * world, N_REGIONS, D_FEAT, seed=0)[rank * B:(rank + 1) * B]
-    items = InstanceList()
-    items.region_features = feats.to(device)
-    if variant == "object_relation_transformer":
-        items.region_boxes = synthetic_boxes(B * world, N_REGIONS, seed=0)[rank * B:(rank + 1) * B].to(device)
+    # every rank holds the same global batch in HBM; decode_sharded hands each rank its contiguous shard
+    from openviic_amd.distributed import decode_sharded
+    feats = synthetic_features(B * world, N_REGIONS, D_FEAT, seed=0).to(device)
+    boxes = synthetic_boxes(B * world, N_REGIONS, seed=0).to(device) if variant == "object_relation_transformer" else None
 
+    def decode(f, b):
+        items = InstanceList()
+        items.region_features = f
+        if b is not None:
+            items.region_boxes = b
+        return model.beam_search(items, batch_size=f.shape[0], beam_size=k, out_size=1)
 
     streams = [torch.cuda.Stream(device=device) for _ in range(max(1, args.streams))]
-    # one gather buffer per stream: batches in flight on different streams never share an output
-    gathered = [torch.empty(world * B, T, dtype=torch.int64, device=device) for _ in streams] if distributed else None
     issued = [0]
 
-    def step():
+    def step(slot=None):
         # consecutive batches are independent: alternate them over the streams (each stream has its own
-        # engine workspace), so a batch's small decode launches overlap the other batch's
-        slot = issued[0] % len(streams)
-        stream = streams[slot]
+        # engine workspace), so a batch's small decode launches overlap the other batch's.  The path's one exchange --
+        # the all-gather of every rank's token ids (RCCL over xGMI, 40 KB per rank, once per batch, on the decoding
+        # stream) -- happens inside decode_sharded.
+        slot = issued[0] % len(streams) if slot is None else slot
         issued[0] += 1
-        with torch.cuda.stream(stream):
-            ids, _ = model.beam_search(items, batch_size=B, beam_size=k, out_size=1)
-            if distributed:
-                # the path's one exchange: token ids of every rank for evaluation (RCCL all-gather over xGMI,
-                # 40 KB per rank, on the decoding stream, once per batch)
-                dist.all_gather_into_tensor(gathered[slot], ids.contiguous())
-        return ids
+        with torch.cuda.stream(streams[slot]):
+            return decode_sharded(decode, feats, boxes)
 
     with torch.no_grad():
         # engine set-up, not measurement: the first call of a (shape, stream) tunes the GEMM tilings and warms every
@@ -211,16 +234,28 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
+    # ---- single-stream leg: a timed region on ONE stream, then the instrumented pass on the same stream -------------
+    single_steps = max(3, args.steps // 3)
+    with torch.no_grad():
+        torch.cuda.synchronize()
+        if distributed:
+            dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(single_steps):
+            step(0)
+        torch.cuda.synchronize()
+        single_ms = 1e3 * (time.perf_counter() - t0) / single_steps
+
     result = None
     if rank == 0:
         from openviic_amd import native
         import ctypes
         lib = native.load()
-        # ---- instrumented pass: hipEvents around every GEMM launch, on the launch stream ----------
-        lib.ovc_profile_kernel_name.restype = ctypes.c_char_p
+        # kernel-scoped events around every GEMM launch of one batch, on the launch stream (plain launches: a replayed
+        # graph cannot carry per-kernel events)
         lib.ovc_profile_enable(1)
-        with torch.no_grad():
-            model.beam_search(items, batch_size=B, beam_size=k, out_size=1)
+        with torch.no_grad(), torch.cuda.stream(streams[0]):
+            decode(feats[:B], None if boxes is None else boxes[:B])
         torch.cuda.synchronize()
         lib.ovc_profile_enable(0)
         def read(kind, index):
@@ -252,7 +287,7 @@ def main():
               % (captions_per_s, 1e3 * elapsed / args.steps, all_gemm, tot_n, 1e3 * tot_ms / max(tot_n, 1)),
               file=sys.stderr, flush=True)
         gflop = GFLOP_PER_CAPTION.get(variant)
-        traffic, traffic_source = profiled_gemm_traffic() if variant.startswith("standard") and B == 256 and k == 5 else (None, None)
+        traffic, traffic_source = profiled_gemm_traffic(variant) if B == 256 and k == 5 else (None, None)
         roofline = {"bound": "mfma", "kernel": "gemm_f32_mfma<BM,BN,WM,WN,WK,BK> (v_mfma_f32_32x32x2_f32), all tilings",
                     "achieved": round(all_gemm, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(all_gemm / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
@@ -261,22 +296,31 @@ def main():
                     "launches_per_step": tot_n, "avg_launch_us": round(1e3 * tot_ms / max(tot_n, 1), 2),
                     "flops_per_launch": round(tot_fl / max(tot_n, 1), 0), "kernel_ms_per_step": round(tot_ms, 3),
                     "timing": "hipExtLaunchKernelGGL start/stop events (dispatch begin/end timestamps) on the launch "
-                              "stream for every GEMM launch of one instrumented batch after the timed region",
+                              "stream for every GEMM launch of one batch decoded on a single stream",
+                    # the mode the kernel durations belong to: one stream, its own timed region of `steps` batches
+                    "single_stream": {"steps": single_steps, "ms_per_step": round(single_ms, 3),
+                                      "captions_per_s": round(B * world / single_ms * 1e3, 1),
+                                      "gemm_share_of_step": round(tot_ms / single_ms, 4)},
+                    # the headline mode: the same GEMM FLOPs per batch over the timed region's wall time per batch
+                    "timed_mode": {"streams": len(streams), "ms_per_step": round(1e3 * elapsed / args.steps, 3),
+                                   "gemm_tflops_over_wall": round(tot_fl / (1e3 * elapsed / args.steps) / 1e9, 2),
+                                   "frac": round(tot_fl / (1e3 * elapsed / args.steps) / 1e9 / PEAK_F32_MFMA_TFLOPS, 4)},
                     "per_kernel": per_kernel, "per_class": per_class}
+        assert tot_ms <= single_ms * 1.02, "GEMM kernel time %.3f ms exceeds the single-stream step %.3f ms" % (tot_ms, single_ms)
         # K1: the padding-mask kernel is the path's one HBM-bound pass over the
         # features (B*N*d_feat fp32 in, B*N bytes out); torch events on the stream it is launched on.
         from openviic_amd import ops
-        feats = items.region_features
+        k1_feats = feats[:B]
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         for _ in range(3):
-            ops.zero_row_mask(feats)
+            ops.zero_row_mask(k1_feats)
         ev0.record()
         for _ in range(20):
-            ops.zero_row_mask(feats)
+            ops.zero_row_mask(k1_feats)
         ev1.record()
         torch.cuda.synchronize()
         k1_us = ev0.elapsed_time(ev1) / 20 * 1e3
-        k1_bytes = feats.numel() * 4 + feats.shape[0] * feats.shape[1]
+        k1_bytes = k1_feats.numel() * 4 + k1_feats.shape[0] * k1_feats.shape[1]
         roofline["k1_hbm"] = {"kernel": "zero_row_mask_kernel", "bound": "hbm", "bytes_per_launch": k1_bytes,
                               "avg_us": round(k1_us, 2), "achieved": round(k1_bytes / k1_us / 1e3, 1), "peak": 8000.0,
                               "unit": "GB/s", "frac": round(k1_bytes / k1_us / 1e3 / 8000.0, 4)}
@@ -296,7 +340,7 @@ def main():
             "roofline": roofline,
         }
         if world == 1 and not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline(cfg, sd, variant, k, args.cpu_sample)
+            result["cpu_baseline"] = cpu_baseline(cfg, sd, variant, k, args.cpu_sample, args.cpu_repeats)
         print(json.dumps(result), flush=True)
     if distributed:
         dist.barrier()

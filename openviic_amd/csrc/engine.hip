@@ -697,15 +697,24 @@ extern "C" int ovc_beam_search_graph(const ovc_model* m, const float* features, 
     evict_lru(key);
 
     TRY(run_encoder_inputs(e, w, features, boxes, B, N));
-    // The legacy null stream cannot be captured (hipErrorStreamCaptureUnsupported): plain launches there.
-    if (e.stream == nullptr) entry.unsupported = true;
+    // The launch sequence is captured on a PRIVATE stream, never on the caller's: while a stream is capturing, HIP
+    // refuses queries of events that were recorded on it earlier (hipErrorCapturedEvent), and other components poll
+    // such events from their own threads -- torch's NCCL watchdog does, for the all-gather that follows each batch.
+    // Kernel nodes carry no stream, so the instantiated graph is launched on the caller's stream as usual.
+    // (The legacy null stream can launch a graph but offers nothing else here; it takes the same path.)
     if (!entry.unsupported && !g_profile_on && entry.calls > 1 && !entry.exec) {
-        if (hipStreamBeginCapture(e.stream, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+        static hipStream_t capture_stream = nullptr;          // guarded by g_graph_mutex
+        if (!capture_stream && hipStreamCreateWithFlags(&capture_stream, hipStreamNonBlocking) != hipSuccess) {
+            (void)hipGetLastError();
+            capture_stream = nullptr;
+            entry.unsupported = true;
+        } else if (hipStreamBeginCapture(capture_stream, hipStreamCaptureModeThreadLocal) != hipSuccess) {
             (void)hipGetLastError();
             entry.unsupported = true;
         } else {
-            const int rc = issue_decode_graph_body(e, w, B, N, k, out_size);
-            const hipError_t end = hipStreamEndCapture(e.stream, &entry.graph);
+            Engine ce{m, capture_stream, 0};
+            const int rc = issue_decode_graph_body(ce, w, B, N, k, out_size);
+            const hipError_t end = hipStreamEndCapture(capture_stream, &entry.graph);
             if (rc != OVC_OK || end != hipSuccess || !entry.graph ||
                 hipGraphInstantiate(&entry.exec, entry.graph, nullptr, nullptr, 0) != hipSuccess) {
                 (void)hipGetLastError();
