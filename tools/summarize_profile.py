@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Condense gpurun_out/<tag>/ (tools/profile_round.sh) into profiles/<tag>_*.{csv,md,json}.
 
-    python tools/summarize_profile.py <tag> [batches_in_trace]
+    python tools/summarize_profile.py <tag> [batches_in_trace] [batches_in_4stream_trace]
+
+<tag> is "<round><letter>[_<config>]", e.g. r02a or r02a_meshed_memory_transformer.
 """
 import collections, csv, glob, json, os, shutil, sys
 
@@ -45,7 +47,7 @@ for counter in ("FETCH_SIZE", "WRITE_SIZE", "SQ_VALU_MFMA_BUSY_CYCLES"):
         cell[1] += float(r["Counter_Value"])
     pmc[counter] = agg
 
-nbatch = float(sys.argv[2]) if len(sys.argv) > 2 else 12.0     # 3 set-up calls + 2 warm-up + 6 steps + 1 instrumented pass
+nbatch = float(sys.argv[2]) if len(sys.argv) > 2 else 15.0     # 3 set-up calls + 2 warm-up + 6 steps + 3 single-stream steps + 1 instrumented pass
 rows = []
 for (kernel, wgs), durs in sorted(per.items(), key=lambda kv: -sum(kv[1])):
     durs.sort()
@@ -72,5 +74,28 @@ with open(os.path.join(dst, "%s_per_kernel_shape.csv" % tag), "w", newline="") a
     wr.writerows(rows)
 total = sum(r["ms_per_batch"] for r in rows)
 print("kernel time per batch: %.2f ms" % total)
+
+# headline mode (4 streams): stats file as rocprofv3 wrote it + per-(kernel, grid) durations under concurrency
+stats4 = glob.glob(os.path.join(src, "trace4", "*", "*_kernel_stats.csv"))
+if stats4:
+    shutil.copy(stats4[0], os.path.join(dst, "%s_kernel_stats_4streams.csv" % tag))
+    trace4 = glob.glob(os.path.join(src, "trace4", "*", "*_kernel_trace.csv"))[0]
+    per4 = collections.defaultdict(list)
+    t_min, t_max = None, None
+    for r in csv.DictReader(open(trace4)):
+        wgs = (int(r["Grid_Size_X"]) // int(r["Workgroup_Size_X"])) * int(r["Grid_Size_Y"]) * int(r["Grid_Size_Z"])
+        per4[(short(r["Kernel_Name"]), wgs)].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+    nb4 = float(sys.argv[3]) if len(sys.argv) > 3 else 12.0 + 12.0 + 1.0 + 3.0   # 12 set-up + 4 warm-up + 8 steps, 3 single-stream, 1 instrumented
+    rows4 = []
+    for (kernel, wgs), durs in sorted(per4.items(), key=lambda kv: -sum(kv[1])):
+        durs.sort()
+        rows4.append({"kernel": kernel, "workgroups": wgs, "launches_per_batch": round(len(durs) / nb4, 1),
+                      "median_us": round(durs[len(durs) // 2], 2), "mean_us": round(sum(durs) / len(durs), 2),
+                      "ms_per_batch": round(sum(durs) / nb4 / 1e3, 3)})
+    with open(os.path.join(dst, "%s_per_kernel_shape_4streams.csv" % tag), "w", newline="") as f:
+        wr = csv.DictWriter(f, fieldnames=list(rows4[0].keys()))
+        wr.writeheader()
+        wr.writerows(rows4)
+    print("4-stream trace: %.2f ms of (overlapping) kernel time per batch" % sum(r["ms_per_batch"] for r in rows4))
 for r in rows[:14]:
     print(r)
