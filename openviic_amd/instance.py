@@ -33,12 +33,15 @@ class Instance(OrderedDict):
 
 
 def _pad_rows(values: Sequence[torch.Tensor], padding_value: float = 0) -> torch.Tensor:
+    """Stack along a new leading dimension, zero-padding ragged first dimensions.  The filler is float32, as in the
+    reference (``utils/instance.py:156-171``: ``torch.zeros(...)``), so ``torch.cat``'s type promotion applies: a padded
+    float64 field stays float64, a padded integer field becomes float32, an unpadded one keeps its dtype."""
     longest = max(v.shape[0] for v in values)
     out = []
     for v in values:
         missing = longest - v.shape[0]
         if missing:
-            filler = torch.full((missing,) + tuple(v.shape[1:]), padding_value, dtype=v.dtype)
+            filler = torch.full((missing,) + tuple(v.shape[1:]), padding_value, dtype=torch.float32)
             v = torch.cat([v, filler], dim=0)
         out.append(v.unsqueeze(0))
     return torch.cat(out, dim=0)

@@ -27,6 +27,10 @@ Fixture families:
   G7  a checkpoint written by the reference (its own initialisation) with its beam-search output
   G8  dual-collaborative (DLCT) embedding + encoder: the reference's own sub-modules composed
       harness-side with the three mask-shape repairs listed in ``g8_dlct_encoder``
+  G9  the prediction loop's input and output sides: ragged per-image feature dicts collated by the reference's
+      ``InstanceList`` (utils/instance.py:33-55,156-171 via data_utils/utils.py:120-121), and the caption strings
+      the reference produces for them end to end (G7 checkpoint -> beam_search(out_size=1) -> Vocab.decode_caption
+      -> groupby collapse, trainers/vi_trainer.py:242-252)
 """
 import argparse
 import os
@@ -315,6 +319,73 @@ def g7_reference_checkpoint(ref, out_dir):
         print("wrote g7_reference_checkpoint_%s.pth (%d tensors)" % (variant, len(model.state_dict())))
 
 
+def g9_instances(seed=17):
+    """The per-image feature dicts of G9, exactly as tests re-create them (numpy float32 / float64 / int64 arrays with
+    ragged first dimensions, a torch tensor field, non-tensor fields)."""
+    rng = np.random.default_rng(seed)
+    out = []
+    for image_id, n in enumerate((5, 7, 3, 6)):
+        out.append(dict(
+            filename="img_%d.jpg" % image_id, image_id=100 + image_id, captions=["caption %d a" % image_id, "caption %d b" % image_id],
+            region_features=rng.standard_normal((n, TINY["d_feature"])).astype(np.float32),
+            region_boxes=np.concatenate([rng.random((n, 2)) * 0.5, 0.5 + rng.random((n, 2)) * 0.5], 1).astype(np.float32),
+            grid_features=torch.from_numpy(rng.standard_normal((4, 6)).astype(np.float32)),      # torch field, not ragged
+            region_scores=rng.random((n, 1)),                                                    # float64, ragged
+            region_labels=rng.integers(0, 9, (n, 2)),                                            # int64, ragged: padding promotes it
+        ))
+    return out
+
+
+def g9_prediction_loop(ref, out_dir):
+    """Input side: ``collate_fn(samples) = InstanceList(samples)`` on ragged Instances.  Output side: the reference's
+    prediction loop on the collated batch with the weights of the G7 checkpoint (its own initialisation)."""
+    import itertools
+    import json
+    from data_utils.vocab import Vocab
+    from utils.instance import Instance
+    s = TINY_SHAPE
+    samples = g9_instances()
+    batch = ref["InstanceList"]([Instance(**d) for d in samples])
+    arrays = {}
+    for key in ("region_features", "region_boxes", "grid_features", "region_scores", "region_labels"):
+        arrays[key] = batch[key].numpy()
+        arrays[key + "_dtype"] = np.array(str(batch[key].dtype))
+    assert batch.batch_size == 4
+    lists = {k: batch[k] for k in ("filename", "image_id", "captions")}
+    # the reference's own prediction loop on that batch (trainers/vi_trainer.py:242-252)
+    variant = "standard_transformer"
+    ckpt = torch.load(os.path.join(out_dir, "g7_reference_checkpoint_%s.pth" % variant), map_location="cpu", weights_only=True)
+    cfg = model_config(variant, **TINY)
+    cfg.DEVICE = "cpu"
+    model = ref["build_model"](cfg, SyntheticVocab(s["V"], s["T"])).eval()
+    model.load_state_dict(ckpt["state_dict"], strict=True)
+    vocab = object.__new__(Vocab)
+    vocab.itos = ["<pad>", "<bos>", "<eos>", "<unk>"] + ["w%02d" % i for i in range(s["V"] - 4)]
+    vocab.specials = vocab.itos[:4]
+    vocab.eos_idx, vocab.max_caption_length = 2, s["T"]
+    recorded = {}
+    import models.modules.beam_search as bs_mod                     # record the decision margins of this run
+    orig_select = bs_mod.BeamSearch.select
+    def select(self, candidate_logprob):
+        flat = candidate_logprob.view(self.b_s, -1)
+        top = torch.sort(flat, -1, descending=True)[0]
+        recorded.setdefault("gap", []).append((top[:, self.beam_size - 1] - top[:, min(self.beam_size, top.shape[1] - 1)]).numpy().copy())
+        return orig_select(self, candidate_logprob)
+    bs_mod.BeamSearch.select = select
+    try:
+        with torch.no_grad():
+            outs, _ = model.beam_search(batch, batch_size=batch.batch_size, beam_size=s["k"], out_size=1)
+    finally:
+        bs_mod.BeamSearch.select = orig_select
+    caps_gen = vocab.decode_caption(outs.contiguous().view(-1, vocab.max_caption_length), join_words=False)
+    gens = [" ".join(k for k, g in itertools.groupby(gen_i)) for gen_i in caps_gen]
+    np.savez_compressed(os.path.join(out_dir, "g9_collated_batch.npz"), beam_ids=outs.numpy(),
+                        gap=np.stack(recorded["gap"]), **arrays)
+    with open(os.path.join(out_dir, "g9_prediction_loop.json"), "w") as f:
+        json.dump({"itos": vocab.itos, "lists": lists, "gens": gens, "beam_size": s["k"]}, f)
+    print("wrote g9_collated_batch.npz / g9_prediction_loop.json:", gens)
+
+
 DLCT_TINY = dict(B=3, n_regions=7, grid=3, d_region=32, d_grid=24, d_model=64, heads=4, d_kv=16, d_ff=128, layers=2)
 
 
@@ -438,6 +509,8 @@ def main():
         g7_reference_checkpoint(ref, HERE)
     if on("g8"):
         g8_dlct_encoder(ref, HERE)
+    if on("g9"):
+        g9_prediction_loop(ref, HERE)
     if on("g2"):
         for v in VARIANTS:
             g2_full(ref, HERE, v)

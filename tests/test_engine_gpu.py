@@ -244,6 +244,42 @@ def test_reference_checkpoint_runs_on_the_engine():
         _logp_close(logp.cpu().numpy()[decided], ckpt["beam_logp"].numpy()[decided], "reference checkpoint " + variant)
 
 
+def test_prediction_loop_end_to_end_matches_the_reference_strings(tmp_path):
+    """The reference's prediction loop (trainers/vi_trainer.py:242-252) on the HIP path, link by link: per-image
+    ``{image_id}.npy`` feature dicts -> collate (zero-padded ragged regions) -> a checkpoint written by the reference
+    -> ``beam_search(items, batch_size=items.batch_size, beam_size, out_size=1)`` -> ``decode_caption`` -> groupby
+    collapse, against the strings the reference itself produced for the same files (G9)."""
+    import importlib.util
+    import json
+    import os
+    from helpers import GOLDEN
+    from openviic_amd.builders import build_model
+    from openviic_amd.checkpoint import load_reference_checkpoint
+    from openviic_amd.config import model_config
+    from openviic_amd.data import batch_from_feature_files
+    from openviic_amd.vocab import WordVocab, captions_from_ids
+    spec = importlib.util.spec_from_file_location("make_goldens", os.path.join(GOLDEN, "make_goldens.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    want = json.load(open(os.path.join(GOLDEN, "g9_prediction_loop.json")))
+    g = golden("g9_collated_batch.npz")
+    paths = []
+    for d in mod.g9_instances():
+        path = str(tmp_path / ("%d.npy" % d["image_id"]))
+        np.save(path, {k: (v.numpy() if isinstance(v, torch.Tensor) else v) for k, v in d.items() if k.endswith(("features", "boxes"))})
+        paths.append(path)
+    items = batch_from_feature_files(paths, trusted=True, device="cuda")
+    assert items.batch_size == 4 and items.filename == [os.path.basename(p) for p in paths]
+    vocab = WordVocab(want["itos"], max_caption_length=TINY_SHAPE["T"])
+    model = build_model(model_config("standard_transformer", device="cuda", **TINY), vocab).eval()
+    load_reference_checkpoint(model, os.path.join(GOLDEN, "g7_reference_checkpoint_standard_transformer.pth"))
+    with torch.no_grad():
+        outs, _ = model.beam_search(items, batch_size=items.batch_size, beam_size=want["beam_size"], out_size=1)
+    assert np.asarray(g["gap"]).min() > MARGIN                      # every decision of the reference run is decided
+    np.testing.assert_array_equal(outs.cpu().numpy(), g["beam_ids"])
+    assert captions_from_ids(vocab, outs) == want["gens"]
+
+
 @pytest.mark.parametrize("variant", ["meshed_memory_transformer", "object_relation_transformer", "attention_on_attention"])
 def test_batch_256_properties_other_architectures(variant):
     """BASELINE configs 3 and 4 (and AoA) at the full batch: halves == whole == first 16 alone, exactly."""

@@ -69,6 +69,50 @@ def test_feature_files_collate_like_the_reference(tmp_path):
     assert load_feature_file(npz)["region_features"].shape == (2, 8)
 
 
+def _g9_instances():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_goldens", os.path.join(GOLDEN, "make_goldens.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)                      # imports only openviic_amd; the reference is touched in main()
+    return mod.g9_instances()
+
+
+def test_collate_matches_the_reference_instance_list(tmp_path):
+    """G9 (f2 pinned): the same ragged per-image dicts through the reference's ``InstanceList`` (fixture) and through
+    ``openviic_amd.instance`` / ``openviic_amd.data``: identical tensors (values, shapes, dtypes incl. the reference's
+    float32-filler promotion), identical non-tensor fields, identical ``batch_size``."""
+    from openviic_amd.data import batch_from_feature_files
+    from openviic_amd.instance import Instance, InstanceList
+    g = np.load(os.path.join(GOLDEN, "g9_collated_batch.npz"))
+    lists = json.load(open(os.path.join(GOLDEN, "g9_prediction_loop.json")))["lists"]
+    samples = _g9_instances()
+    batch = InstanceList([Instance(**d) for d in samples])
+    assert batch.batch_size == 4 and batch.get_fields() == list(samples[0].keys())
+    for key in ("region_features", "region_boxes", "grid_features", "region_scores", "region_labels"):
+        assert str(batch[key].dtype) == str(g[key + "_dtype"]), key
+        np.testing.assert_array_equal(batch[key].numpy(), g[key], err_msg=key)
+    assert tuple(batch.region_features.shape) == (4, 7, TINY["d_feature"]) and batch.region_labels.dtype == torch.float32
+    for key, want in lists.items():
+        assert batch[key] == want, key
+    assert batch.missing is None and batch.to("cpu").region_boxes.shape == (4, 7, 4)
+    # the same images from {image_id}.npy files, the reference's on-disk format (data_utils/dataset.py:88-92)
+    paths = []
+    for d in samples:
+        path = str(tmp_path / ("%d.npy" % d["image_id"]))
+        np.save(path, {k: (v.numpy() if isinstance(v, torch.Tensor) else v) for k, v in d.items() if k.endswith(("features", "boxes"))})
+        paths.append(path)
+    from_files = batch_from_feature_files(paths, trusted=True)
+    for key in ("region_features", "region_boxes", "grid_features"):
+        np.testing.assert_array_equal(from_files[key].numpy(), g[key], err_msg=key)
+    # ... and the oracle decodes that batch to the ids / strings the reference's prediction loop produced
+    want = json.load(open(os.path.join(GOLDEN, "g9_prediction_loop.json")))
+    ckpt = torch.load(os.path.join(GOLDEN, "g7_reference_checkpoint_standard_transformer.pth"), map_location="cpu", weights_only=True)
+    cfg = model_config("standard_transformer", device="cpu", **TINY)
+    ids, _ = OracleCaptioner(cfg, ckpt["state_dict"], TINY_SHAPE["V"], TINY_SHAPE["T"]).beam_search(from_files.region_features, want["beam_size"])
+    np.testing.assert_array_equal(ids.numpy(), g["beam_ids"])
+    assert captions_from_ids(WordVocab(want["itos"], TINY_SHAPE["T"]), ids) == want["gens"]
+
+
 # ---- dual-collaborative encoder: host-side logic (no device work) --------------------------------------------
 
 def test_grid_visibility_mask_matches_reference_cell_lookup():
