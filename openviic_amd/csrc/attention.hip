@@ -7,8 +7,9 @@
 //                          the softmax row reduce on wavefront shuffles.
 //  decode_self_attention   one query row per beam against its own history through the ancestor
 //                          table (no cache re-ordering), nq = 1.
-//  decode_cross_attention  the k beams of one image share that image's projected encoder K/V,
-//                          staged once in LDS per (image, head).
+//  decode_cross_attention  the k beams of one image share that image's projected encoder K/V: one wave per
+//                          (image, head), everything in registers, both contractions on v_mfma_f32_16x16x4_f32
+//                          (d_k in {16, 32, 64}); head sizes 4 and 8 take an LDS-staged VALU kernel.
 //
 // Reference call sites: models/modules/attentions.py:51-55, :102-111, :171-183.
 #include "common.h"
@@ -437,7 +438,8 @@ __global__ __launch_bounds__(256) void decode_cross_attention_mfma_kernel(Decode
     }
 }
 
-// Fallback for head sizes that are not multiples of 16: K/V of one (image, head) staged in LDS, VALU dots.
+// Head sizes 4 and 8 (not multiples of the 16-deep MFMA k block): K/V of one (image, head) staged in LDS, VALU dots.
+// Exercised by tests/test_engine_gpu.py::test_unusual_dimensions_against_oracle (d_k = 8 and d_k = 4 cases).
 __global__ __launch_bounds__(256) void decode_cross_attention_lds_kernel(DecodeCrossArgs p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;

@@ -4,7 +4,8 @@ Parameter names, shapes and initialisation follow the reference
 (``models/modules/attentions.py:9-58`` plain, ``:61-114`` geometry, ``:117-185`` memory,
 ``:270-318`` multi-head wrapper) so that reference checkpoints load key-for-key.  The arithmetic
 runs in the HIP library: projections through the fp32 MFMA GEMM (``ovc_linear``), the
-scale / mask / softmax / weighted-sum through ``ovc_attention``; nothing here falls back to ATen.
+scale / mask / softmax / weighted-sum through ``ovc_attention``; no operator here falls back to ATen
+(shape glue such as ``view`` / ``cat`` of cached state is ordinary tensor code -- see ``ops.py``).
 """
 import math
 

@@ -1,7 +1,13 @@
 """Operator-level Python wrappers over the HIP library (one function per ``ovc_*`` operator).
 
 Inputs must be fp32 tensors on the HIP device; outputs are freshly allocated with ``torch.empty``
-(PyTorch is only the allocator here).  Anything else raises: there is no ATen fallback.
+(PyTorch is only the allocator here).  Anything else raises: there is no ATen fallback for any operator.
+
+Scope of that statement: every contraction, normalisation, softmax, selection and embedding on this step-wise
+API is a HIP kernel of ``libovc.so``.  The glue AROUND the operators in ``openviic_amd/modules`` -- adding a
+positional table to a combined stream, copying a level into a stacked buffer, ``alive * (prev != eos)``,
+``cat`` / ``gather`` of decode state in the host-loop beam search -- is plain tensor arithmetic on the device
+(ATen).  That glue is off the production path: ``beam_search(fused=True)`` runs entirely inside the engine.
 """
 from typing import Optional, Tuple
 
