@@ -35,32 +35,21 @@ __device__ __forceinline__ Cand wave_best(Cand c) {
     return c;
 }
 
-// Insert (cv, ci) into a descending sorted list of length k (k <= kMaxK) held in registers.
-__device__ __forceinline__ void list_insert(float (&lv)[kMaxK], int (&li)[kMaxK], int k, float cv, int ci) {
+// The k-th largest (with multiplicity) of the 64 lane values of a wave, exactly: a binary search over the bits of the
+// order-preserving integer image of a float, one ballot + population count per bit and no cross-lane data movement
+// (k rounds of a 6-step shuffle arg-max cost ~10x the latency).  NaN lanes count as the smallest value.
+__device__ __forceinline__ float wave_kth_largest(float v, int k) {
+    const unsigned bits = __float_as_uint(v);
+    const unsigned key = (v != v) ? 0u : ((bits & 0x80000000u) ? ~bits : (bits | 0x80000000u));   // monotone in v
+    unsigned t = 0;
 #pragma unroll
-    for (int s = 0; s < kMaxK; ++s) {
-        if (s < k && better(cv, ci, lv[s], li[s])) {
-            const float tv = lv[s]; const int ti = li[s];
-            lv[s] = cv; li[s] = ci; cv = tv; ci = ti;
-        }
+    for (int bit = 31; bit >= 0; --bit) {
+        const unsigned cand = t | (1u << bit);
+        if (__popcll(__ballot(key >= cand)) >= k) t = cand;
     }
-}
-
-// k rounds of wave-wide argmax over the heads of the lanes' sorted lists: after the call lane r (r < k)
-// of the wave holds the wave's r-th best candidate.
-__device__ __forceinline__ Cand wave_topk(const float (&lv)[kMaxK], const int (&li)[kMaxK], int k, int lane) {
-    int head = 0;
-    Cand mine; mine.v = -INFINITY; mine.idx = 0x7fffffff;
-    for (int round = 0; round < k; ++round) {
-        Cand c; c.v = -INFINITY; c.idx = 0x7fffffff;
-#pragma unroll
-        for (int s = 0; s < kMaxK; ++s)
-            if (s == head) { c.v = lv[s]; c.idx = li[s]; }
-        const Cand w = wave_best(c);
-        if (c.idx == w.idx && w.idx != 0x7fffffff) ++head;     // candidate indices are unique
-        if (lane == round) mine = w;
-    }
-    return mine;
+    if (t == 0u) return -INFINITY;                       // fewer than k comparable values
+    const unsigned back = (t & 0x80000000u) ? (t & 0x7fffffffu) : ~t;
+    return __uint_as_float(back);
 }
 
 // One workgroup (256 threads) per beam row -- B*width workgroups, several resident per CU, so one row's
@@ -71,7 +60,9 @@ __device__ __forceinline__ Cand wave_topk(const float (&lv)[kMaxK], const int (&
 // lane maxima bounds the row's k-th best from below, so only the few candidates at or above the largest such
 // bound are collected (LDS list) and ranked by one wave.  The image's k winners are the k best of its rows'
 // candidates (merged by beam_update_kernel / beam_merge_kernel with the same order: score, then flat index).
-template <int kPerThread, int kVec>
+// kMasked: the caller wants the masked log-probabilities of every word written out (return_probs); the hot path does
+// not, and then neither the stores nor their address arithmetic exist in the instruction stream.
+template <int kPerThread, int kVec, bool kMasked>
 __global__ __launch_bounds__(kSelThreads) void beam_row_select_kernel(BeamSelectArgs p) {
     constexpr int kElems = kPerThread * kVec;      // logits per thread; element (j, e) is column kVec*(tid + j*256) + e
     constexpr int kWaves = kSelThreads / 64;
@@ -90,7 +81,7 @@ __global__ __launch_bounds__(kSelThreads) void beam_row_select_kernel(BeamSelect
     float* cand_v = p.cand_v + (size_t)row * k;
     int* cand_i = p.cand_i + (size_t)row * k;
 
-    if (!live && !p.masked_logp) {
+    if (!live && !kMasked) {
         // A frozen beam (it has emitted <eos>) offers word 0 at its running score and -999 for every other word
         // (beam_search.py:52-55): its k best are words 0..k-1, whatever the logits are.
         if (tid < k) {
@@ -151,14 +142,14 @@ __global__ __launch_bounds__(kSelThreads) void beam_row_select_kernel(BeamSelect
     // increasing order, hence a strict > keeps the lower index on ties.
     float bv = -INFINITY;
     int bi = 0x7fffffff;
-    float* mrow = p.masked_logp ? p.masked_logp + (size_t)row * V : nullptr;
+    float* mrow = kMasked ? p.masked_logp + (size_t)row * V : nullptr;
 #pragma unroll
     for (int j = 0; j < kElems; ++j) {
         const int c = kVec * (tid + (j / kVec) * kSelThreads) + (j % kVec);
         float cand = -INFINITY;
         if (c < V) {
             const float lp = (xv[j] - mx) - ls;
-            if (mrow) mrow[c] = lp * alive;
+            if (kMasked) mrow[c] = lp * alive;
             cand = live ? run + lp : (c == 0 ? run : -999.0f);
             if (cand > bv) { bv = cand; bi = i * V + c; }
         }
@@ -168,15 +159,7 @@ __global__ __launch_bounds__(kSelThreads) void beam_row_select_kernel(BeamSelect
     // ---- a lower bound on the row's k-th best: the k-th best of one wave's lane maxima (k distinct candidates
     //      are >= it), tightened by taking the largest such bound over the waves ---------------------------------------
     {
-        float cv = bv;
-        int ci = bi;
-        float kth = -INFINITY;
-        for (int round = 0; round < k; ++round) {
-            Cand c; c.v = cv; c.idx = ci;
-            const Cand w = wave_best(c);
-            kth = w.idx != 0x7fffffff ? w.v : -INFINITY;
-            if (ci == w.idx) { cv = -INFINITY; ci = 0x7fffffff; }
-        }
+        const float kth = wave_kth_largest(bv, k);
         if (lane == 0) thr[wave] = kth;
         if (tid == 0) count = 0;
     }
@@ -224,14 +207,17 @@ __global__ __launch_bounds__(kSelThreads) void beam_row_select_kernel(BeamSelect
         }
         return;
     }
-    if (wave != 0) return;
-    float mv[kMaxK];
-    int mi[kMaxK];
-#pragma unroll
-    for (int s = 0; s < kMaxK; ++s) { mv[s] = -INFINITY; mi[s] = 0x7fffffff; }
-    for (int e = lane; e < nsurv; e += 64) list_insert(mv, mi, k, surv_v[e], surv_i[e]);
-    const Cand best = wave_topk(mv, mi, k, lane);
-    if (lane < k) { cand_v[lane] = best.v; cand_i[lane] = best.idx; }
+    // ---- rank the survivors: a survivor's rank is the number of survivors that beat it in the (score desc, flat
+    //      index asc) order -- a strict total order, so ranks are unique and ranks 0..k-1 are the row's k best.  Every
+    //      thread ranks its share against the whole list with broadcast LDS reads; no shuffles, no sorted lists.
+    for (int e = tid; e < nsurv; e += kSelThreads) {
+        const float v = surv_v[e];
+        const int idx = surv_i[e];
+        int rank = 0;
+        for (int o = 0; o < nsurv; ++o) rank += better(surv_v[o], surv_i[o], v, idx) ? 1 : 0;
+        if (rank < k) { cand_v[rank] = v; cand_i[rank] = idx; }
+    }
+    if (tid >= nsurv && tid < k) { cand_v[tid] = -INFINITY; cand_i[tid] = 0x7fffffff; }     // fewer than k candidates exist
 }
 
 // Any vocabulary size: the row is streamed from memory instead of held in registers -- one pass for the maximum,
@@ -414,7 +400,11 @@ int ovc_beam_select_launch(const BeamSelectArgs& p, int B, hipStream_t stream) {
     if ((long)p.width * p.V < p.k || (long)p.width * p.V > 0x7fffffffL) return OVC_EINVAL;
     const dim3 grid(B * p.width), block(kSelThreads);
     const bool vec = (p.ld & 3) == 0 && ovc_aligned16(p.logits);
-#define OVC_SELECT(PT, VEC) hipLaunchKernelGGL((beam_row_select_kernel<PT, VEC>), grid, block, 0, stream, p)
+#define OVC_SELECT(PT, VEC)                                                                                        \
+    do {                                                                                                           \
+        if (p.masked_logp) hipLaunchKernelGGL((beam_row_select_kernel<PT, VEC, true>), grid, block, 0, stream, p);  \
+        else hipLaunchKernelGGL((beam_row_select_kernel<PT, VEC, false>), grid, block, 0, stream, p);               \
+    } while (0)
 #define OVC_SELECT_STREAMING() hipLaunchKernelGGL(beam_row_select_streaming_kernel, grid, block, 0, stream, p)
     if (vec) {
         const int per_thread = (p.V + 4 * kSelThreads - 1) / (4 * kSelThreads);      // 16-byte loads
