@@ -63,7 +63,7 @@ __device__ __forceinline__ float wave_kth_largest(float v, int k) {
 // kMasked: the caller wants the masked log-probabilities of every word written out (return_probs); the hot path does
 // not, and then neither the stores nor their address arithmetic exist in the instruction stream.
 template <int kPerThread, int kVec, bool kMasked>
-__global__ __launch_bounds__(kSelThreads) void beam_row_select_kernel(BeamSelectArgs p) {
+__global__ __launch_bounds__(kSelThreads, (kPerThread * kVec <= 40 && !kMasked ? 5 : 1)) void beam_row_select_kernel(BeamSelectArgs p) {
     constexpr int kElems = kPerThread * kVec;      // logits per thread; element (j, e) is column kVec*(tid + j*256) + e
     constexpr int kWaves = kSelThreads / 64;
     __shared__ float red[kWaves];
@@ -93,6 +93,7 @@ __global__ __launch_bounds__(kSelThreads) void beam_row_select_kernel(BeamSelect
     }
 
     const float* x = p.logits + (size_t)row * p.ld;
+    const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, p.ld * 4, 0x00020000);
     float xv[kElems];
 #pragma unroll
     for (int j = 0; j < kPerThread; ++j) {
@@ -100,7 +101,10 @@ __global__ __launch_bounds__(kSelThreads) void beam_row_select_kernel(BeamSelect
         // unconditional loads from clamped (always valid) addresses; the tail is masked afterwards, so that all of
         // a thread's loads are in flight together (a guarded load costs a vmcnt(0) each)
         if (kVec == 4) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(x + min(c0, (V - 1) & ~3));   // rows are 16-byte aligned
+            // raw buffer loads: one 32-bit lane offset for all of the thread's loads, the column block in the scalar
+            // offset, the row's end in the descriptor (reads past it return 0 and are masked below) -- no per-load
+            // 64-bit address registers, which is what keeps this kernel at five waves per SIMD
+            const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, tid * 16, j * kSelThreads * 16, 0));
 #pragma unroll
             for (int e = 0; e < 4; ++e) xv[j * 4 + e] = c0 + e < V ? v[e] : -INFINITY;
         } else {
