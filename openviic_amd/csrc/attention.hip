@@ -364,15 +364,18 @@ __global__ __launch_bounds__(256) void decode_cross_attention_mfma_kernel(Decode
         for (int S = 0; S < SB; ++S) qf[S] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
 
+    // NT independent accumulation chains, issued round-robin: a 16x16x4 MFMA can issue every 32 cycles but its result is
+    // only available to a dependent one after 40, so one chain at a time would stall on every instruction.  The sum
+    // over d inside each key tile keeps its order (S, then e).
     f32x4 st[NT];
 #pragma unroll
-    for (int T = 0; T < NT; ++T) {
-        st[T] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int T = 0; T < NT; ++T) st[T] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int S = 0; S < SB; ++S)
+    for (int S = 0; S < SB; ++S)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) st[T] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[T][S][e], qf[S][e], st[T], 0, 0, 0);
-    }
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int T = 0; T < NT; ++T) st[T] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[T][S][e], qf[S][e], st[T], 0, 0, 0);
 
     // ---- V loads are issued before the softmax arithmetic so that they are in flight meanwhile ------------------
     const int vc = 4 * min(r, (p.dv >> 2) - 1);

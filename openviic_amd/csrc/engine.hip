@@ -41,7 +41,7 @@ namespace {
 // ---------------------------------------------------------------------------------------------
 struct ProfileRecord { hipEvent_t start, stop; double flops; int cls, tiling; };
 struct ProfileBin { int64_t launches; double ms, flops; };
-constexpr int kProfileTilings = 16;
+constexpr int kProfileTilings = 32;
 std::atomic<bool> g_profile_on{false};
 std::mutex g_profile_mutex;                      // guards everything below (several host threads may decode at once)
 std::vector<ProfileRecord> g_profile;            // open records (events not yet resolved)

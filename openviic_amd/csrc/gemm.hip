@@ -36,7 +36,7 @@
 //                    wave-level parallelism of one chain without changing a single bit of the result.
 //     The class is chosen by the CALL SITE (engine: 1 for the M = B*N encoder-side products, 4 for the
 //     M = B*k decode-step products), never by the tuner; ovc_gemm_tune only ranks tilings inside it.
-//   * Fifteen tilings (128x128 ... 32x32; K tile 32 or 64); ovc_gemm_tune measures the ones of the requested
+//   * Seventeen tilings (128x128 ... 32x32; K tile 16, 32 or 64); ovc_gemm_tune measures the ones of the requested
 //     class per shape, a cost model covers shapes that were never measured.
 #include <atomic>
 #include <mutex>
@@ -71,7 +71,7 @@ struct TileConfig {
     static constexpr int kLdsFloats = 2 * (BM + BN) * LDT;
     static_assert(WM * WN * WK == 4, "four waves per workgroup");
     static_assert(kChains == 1 || kChains == 4, "K-order classes: one chain or four");
-    static_assert(BK % 32 == 0, "a K tile holds whole 4-group periods of the chain assignment");
+    static_assert(BK % 8 == 0 && (kChains == 1 || BK % 32 == 0), "a K tile holds whole 8-deep groups (four chains: whole 4-group periods)");
     static_assert(kWaveM % 32 == 0 && kWaveN % 32 == 0, "wave tile must be a multiple of 32x32");
     static_assert(kLoadA >= 1 && kLoadB >= 1, "tile too small for 256 loader threads");
     static_assert((WK - 1) * NC * BM * BN <= kLdsFloats, "chain reduction must fit in the tile buffers");
@@ -414,7 +414,10 @@ struct TilingInfo { int bm, bn, wm, wn, wk, bk, nc; };
     /* four chains (kchains = 4): in one wave, in two, in four */                                        \
     X(6, 64, 128, 2, 2, 1, 32, 4) X(7, 64, 64, 2, 2, 1, 32, 4) X(8, 64, 64, 2, 2, 1, 64, 4)             \
     X(9, 32, 64, 1, 2, 2, 32, 2) X(10, 64, 32, 2, 1, 2, 32, 2) X(11, 32, 64, 1, 2, 2, 64, 2)            \
-    X(12, 64, 32, 2, 1, 2, 64, 2) X(13, 32, 32, 1, 1, 4, 32, 1) X(14, 32, 32, 1, 1, 4, 64, 1)
+    X(12, 64, 32, 2, 1, 2, 64, 2) X(13, 32, 32, 1, 1, 4, 32, 1) X(14, 32, 32, 1, 1, 4, 64, 1)          \
+    /* one chain, shallow K tiles: half the LDS per workgroup -> twice the workgroups per CU, whose prologues and */ \
+    /* epilogues then overlap other workgroups' MFMA (the fixed cost per round of workgroups drops by a third)   */ \
+    X(15, 64, 64, 2, 2, 1, 16, 1) X(16, 128, 128, 2, 2, 1, 16, 1)
 //  (K tiles of 128 were tried for the small tilings: slower -- 15.6 vs 12.2 us on 1280x512x512)
 #define OVC_TILING_INFO(id, bm, bn, wm, wn, wk, bk, nc) {bm, bn, wm, wn, wk, bk, nc},
 constexpr TilingInfo kTilings[] = {OVC_TILINGS(OVC_TILING_INFO)};

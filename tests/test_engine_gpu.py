@@ -310,7 +310,7 @@ def test_results_do_not_depend_on_the_gemm_tiling():
             t += 1
     finally:
         lib.ovc_debug_force_gemm_tiling(-1)
-    assert t == 15
+    assert t == 17
 
 
 def test_hipgraph_replay_matches_plain_launches():

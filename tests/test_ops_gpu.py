@@ -404,7 +404,7 @@ def test_every_tiling_of_a_k_order_class_gives_the_same_bits(M, N, K):
     want = x.double() @ w.double().T + b.double()
     xd, wd, bd = (t.to(DEV) for t in (x, w, b))
     tilings = _tilings(lib)
-    assert len(tilings) == 15 and {c for _, _, c in tilings} == {1, 4}
+    assert len(tilings) == 17 and {c for _, _, c in tilings} == {1, 4}
     first = {}
     for t, name, chains in tilings:
         rc, got = _linear_by_tiling(lib, native, xd, wd, bd, t)
