@@ -2,7 +2,7 @@
 # A/B timing on ONE box: the in-tree libovc.so against another build of the same ABI (tools/libovc_prev.bin),
 # alternating, 3 streams and 1 stream.   tools/ab_bench.sh [rounds]
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
-PREV=$ROOT/tools/libovc_prev.bin
+PREV=$ROOT/tools/libovc_base.bin
 for i in $(seq 1 ${1:-2}); do
   for S in 4 1; do
     echo -n "new  streams=$S: "; python3 $ROOT/bench.py --no-cpu-baseline --streams $S 2>&1 >/dev/null | tail -1 | cut -c1-60
