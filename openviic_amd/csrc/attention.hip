@@ -12,6 +12,9 @@
 //                          (d_k in {16, 32, 64}); head sizes 4 and 8 take an LDS-staged VALU kernel.
 //
 // Reference call sites: models/modules/attentions.py:51-55, :102-111, :171-183.
+#include <cstdlib>
+#include <mutex>
+
 #include "common.h"
 
 namespace {
@@ -158,6 +161,179 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(AttnArgs p) {
     }
 }
 
+
+// -------------------------------------------------------------------------------------------------
+// attention_regs_kernel: the same operator with the scores kept in accumulator registers.
+//
+// One workgroup per (image, head); wave w owns queries 32 w .. 32 w + 31 and ALL keys.  K and V of the (image,
+// head) go to LDS once with fully coalesced 256-byte row reads and are shared by the waves; each wave's Q fragment
+// comes straight from global memory into registers.
+//   S^T[key][q] = K Q^T  (v_mfma_f32_32x32x2_f32, A = K rows from LDS, B = Q rows): the accumulator of key tile tk
+//       has the QUERY on the lane (q = lane & 31) and 16 keys on its registers (key = 32 tk + (r&3) + 8 (r>>2) +
+//       4 (lane>>5)), so scale, mask, geometry bias and the softmax over keys are register arithmetic plus ONE
+//       __shfl_xor(32) per reduction -- no score image in LDS, no scalar LDS stores (the general kernel above
+//       spends most of its time there: 0.13 of the MFMA peak).
+//   O^T[dv][q] = V^T P^T: the probabilities are used where they are, as the B operand: MFMA step (tk, r) contracts
+//       over the two keys base_r and base_r + 4 that the two lane halves hold in register r; the A operand
+//       V[key][dv = lane & 31] is a conflict-free 128-byte ds_read_b32 per half.
+//   The output tile goes through LDS once (the K image is free by then) so that rows leave as whole 256-byte lines.
+// NKT = key tiles of 32 (real keys + memory slots, <= 4); KG = 8-deep d groups of Q.K (dk <= 8 KG);
+// DVT = 32-wide tiles of d_v.  Numerics: scores and probabilities as in the general kernel (same scale, mask,
+// geometry order, expf, division); only the order of the softmax sum and of the P.V sum over keys differs.
+// -------------------------------------------------------------------------------------------------
+template <int NKT, int KG, int DVT>
+__global__ __launch_bounds__(256) void attention_regs_kernel(AttnArgs p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int hd = blockIdx.x % p.h, b = blockIdx.x / p.h;
+    const int nkt = p.nk + p.m;
+    constexpr int kRows = NKT * 32;
+    const int k_rows = max(kRows, ((p.nq + 31) >> 5) * 32);           // the K image doubles as the output staging area
+    float* Ks = lds;                          // [k_rows][68]
+    float* Vs = Ks + k_rows * kLdQK;          // [kRows][68]
+
+    // ---- K, V -> LDS (zero-filled outside the valid region), Q fragment -> registers ------------------------------
+    // All 256 threads stage (waves beyond the query tiles only help here), and all of a thread's global loads are
+    // issued before the first LDS store: a load -> store loop would pay one memory round trip per pass.
+    {
+        const int c4 = tid & 15, col = c4 * 4, r0 = tid >> 4;
+        constexpr int kPasses = kRows / 16;
+        f32x4 kv[kPasses], vv[kPasses];
+#pragma unroll
+        for (int i = 0; i < kPasses; ++i) {
+            const int r = r0 + 16 * i;
+            const bool real = r < p.nk, slot = !real && r < nkt;
+            const int mr = min(max(r - p.nk, 0), max(p.m - 1, 0));
+            // one address per matrix, always valid: a real key row, a memory slot, or (padding) row 0 -- zeroed below
+            const float* ks = slot ? p.mem_k + (size_t)mr * (p.h * p.dk) + hd * p.dk
+                                   : p.k + ((size_t)b * p.nk + (real ? r : 0)) * (p.h * p.dk) + hd * p.dk;
+            const float* vs = slot ? p.mem_v + (size_t)mr * (p.h * p.dv) + hd * p.dv
+                                   : p.v + ((size_t)b * p.nk + (real ? r : 0)) * (p.h * p.dv) + hd * p.dv;
+            kv[i] = *reinterpret_cast<const f32x4*>(ks + min(col, p.dk - 4));
+            vv[i] = *reinterpret_cast<const f32x4*>(vs + min(col, p.dv - 4));
+        }
+#pragma unroll
+        for (int i = 0; i < kPasses; ++i) {
+            const int r = r0 + 16 * i;
+            const bool real = r < p.nk, slot = !real && r < nkt;
+            f32x4 kx = kv[i], vx = vv[i];
+            if (slot) { kx = kx * p.mem_scale_k; vx = vx * p.mem_scale_v; }
+            if ((!real && !slot) || col >= p.dk) kx = f32x4{0.f, 0.f, 0.f, 0.f};
+            if ((!real && !slot) || col >= p.dv) vx = f32x4{0.f, 0.f, 0.f, 0.f};
+            *reinterpret_cast<f32x4*>(Ks + r * kLdQK + col) = kx;
+            *reinterpret_cast<f32x4*>(Vs + r * kLdQK + col) = vx;
+        }
+    }
+    const int qwaves = (p.nq + 31) >> 5;                        // waves that own queries; the others only staged
+    const int qi = lane & 31, half = lane >> 5;
+    const int gq = wave * 32 + qi;                              // this lane's query
+    const bool q_ok = gq < p.nq;
+    f32x4 qf[KG];
+    {
+        const float* qrow = p.q + ((size_t)b * p.nq + min(gq, p.nq - 1)) * (p.h * p.dk) + hd * p.dk;
+#pragma unroll
+        for (int kk = 0; kk < KG; ++kk) {
+            const int d = 8 * kk + 4 * half;
+            qf[kk] = *reinterpret_cast<const f32x4*>(qrow + min(d, p.dk - 4));
+            if (!q_ok || d >= p.dk) qf[kk] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    __syncthreads();
+
+    // ---- S^T = K Q^T ---------------------------------------------------------------------------------------------------
+    f32x16 st[NKT];
+#pragma unroll
+    for (int tk = 0; tk < NKT; ++tk)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) st[tk][r] = 0.f;
+    if (wave < qwaves) {
+#pragma unroll
+    for (int kk = 0; kk < KG; ++kk) {
+        f32x4 kf[NKT];
+#pragma unroll
+        for (int tk = 0; tk < NKT; ++tk) kf[tk] = *reinterpret_cast<const f32x4*>(Ks + (tk * 32 + qi) * kLdQK + 8 * kk + 4 * half);
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int tk = 0; tk < NKT; ++tk) st[tk] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[tk][s], qf[kk][s], st[tk], 0, 0, 0);
+    }
+    }
+    __syncthreads();                                            // every wave is done with the K image
+    if (wave >= qwaves) return;
+
+    // ---- scale, mask, geometry bias; softmax over the keys of this lane's query -------------------------------------------
+    const float inv_scale = sqrtf((float)p.dk);
+    const uint8_t* mrow = p.mask ? p.mask + (size_t)b * p.mask_sb + (size_t)min(gq, p.nq - 1) * p.mask_sq : nullptr;
+    const float* grow = p.geometry ? p.geometry + (((size_t)b * p.h + hd) * p.nq + min(gq, p.nq - 1)) * p.nk : nullptr;
+    float mx = -INFINITY;
+#pragma unroll
+    for (int tk = 0; tk < NKT; ++tk)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int kj = tk * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            float s = st[tk][r] / inv_scale;
+            if (kj >= nkt) {
+                s = -INFINITY;
+            } else if (kj < p.nk) {
+                if (mrow && mrow[kj]) s = -INFINITY;
+                if (grow) s = logf(fmaxf(grow[kj], 1e-6f)) + s;
+            }
+            st[tk][r] = s;
+            mx = fmaxf(mx, s);
+        }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int tk = 0; tk < NKT; ++tk)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float e = expf(st[tk][r] - mx);
+            st[tk][r] = e;
+            sum += e;
+        }
+    sum += __shfl_xor(sum, 32, 64);
+#pragma unroll
+    for (int tk = 0; tk < NKT; ++tk)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) st[tk][r] = st[tk][r] / sum;
+
+    // ---- O^T = V^T P^T ---------------------------------------------------------------------------------------------------
+    f32x16 ot[DVT];
+#pragma unroll
+    for (int t = 0; t < DVT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ot[t][r] = 0.f;
+#pragma unroll
+    for (int tk = 0; tk < NKT; ++tk)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float* vrow = Vs + (tk * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * kLdQK + qi;     // this half's key of step (tk, r)
+#pragma unroll
+            for (int t = 0; t < DVT; ++t) ot[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(vrow[t * 32], st[tk][r], ot[t], 0, 0, 0);
+        }
+
+    // ---- output: accumulator (dv on registers, query on the lane) -> LDS [query][dv] -> whole rows to memory ---------------
+    float* Os = Ks + wave * 32 * kLdQK;
+#pragma unroll
+    for (int t = 0; t < DVT; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            *reinterpret_cast<f32x4*>(Os + qi * kLdQK + t * 32 + 8 * j + 4 * half) =
+                f32x4{ot[t][4 * j], ot[t][4 * j + 1], ot[t][4 * j + 2], ot[t][4 * j + 3]};
+    // (each wave reads back only what it wrote itself: no workgroup barrier, the compiler's lgkmcnt wait orders it)
+    {
+        const int c4 = lane & 15, col = c4 * 4;
+#pragma unroll
+        for (int pass = 0; pass < 8; ++pass) {
+            const int row = pass * 4 + (lane >> 4);
+            const int oq = wave * 32 + row;
+            if (oq < p.nq && col < p.dv)
+                *reinterpret_cast<f32x4*>(p.out + ((size_t)b * p.nq + oq) * (p.h * p.dv) + hd * p.dv + col) =
+                    *reinterpret_cast<const f32x4*>(Os + row * kLdQK + col);
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int ovc_attention(const float* q, const float* k, const float* v, int b, int nq, int nk, int h,
@@ -177,6 +353,34 @@ extern "C" int ovc_attention(const float* q, const float* k, const float* v, int
     p.mem_k = mem_k; p.mem_v = mem_v; p.m = m; p.mem_scale_k = mem_scale_k; p.mem_scale_v = mem_scale_v;
     p.nkp = ((nk + m + 31) / 32) * 32;
     p.qtiles = (nq + kQTile - 1) / kQTile;
+    // Register-resident kernel: one workgroup per (image, head), a wave per 32 queries (nq <= 128), scores never leave
+    // the accumulators.  Head sizes up to 64, key tiles up to 4 x 32: everything the path uses.
+    {
+        const int nkt = (nk + m + 31) / 32, waves = (nq + 31) / 32, hmax = dk > dv ? dk : dv;
+        if (nkt <= 4 && waves <= 4 && !getenv("OVC_ATTENTION_GENERAL")) {
+            const int k_rows = nkt * 32 > waves * 32 ? nkt * 32 : waves * 32;
+            const size_t bytes = sizeof(float) * (size_t)(k_rows + nkt * 32) * kLdQK;
+            const dim3 grid(b * h), block(256);
+#define OVC_ATT(NKT, KG, DVT)                                                                                         \
+    do {                                                                                                              \
+        static std::once_flag once;                                                                                   \
+        std::call_once(once, [] {                                                                                     \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attention_regs_kernel<NKT, KG, DVT>),            \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);                         \
+        });                                                                                                           \
+        hipLaunchKernelGGL((attention_regs_kernel<NKT, KG, DVT>), grid, block, bytes, ovc_hip_stream(stream), p);     \
+    } while (0)
+#define OVC_ATT_H(NKT)                                                                                                \
+    do {                                                                                                              \
+        if (hmax <= 16) OVC_ATT(NKT, 2, 1); else if (hmax <= 32) OVC_ATT(NKT, 4, 1); else OVC_ATT(NKT, 8, 2);          \
+    } while (0)
+            if (nkt == 1) OVC_ATT_H(1); else if (nkt == 2) OVC_ATT_H(2); else if (nkt == 3) OVC_ATT_H(3); else OVC_ATT_H(4);
+#undef OVC_ATT_H
+#undef OVC_ATT
+            OVC_RETURN_IF_LAUNCH_FAILED();
+            return OVC_OK;
+        }
+    }
     const size_t lds_bytes = sizeof(float) * ((size_t)kQTile * kLdQK + 2 * (size_t)p.nkp * kLdQK + (size_t)kQTile * (p.nkp + 4));
     static bool attr_set = false;
     if (!attr_set) {
