@@ -130,6 +130,29 @@ def test_attention(b, nq, nk, h, dk, kind):
     _close(got, want, what="attention %s" % kind)
 
 
+def test_attention_general_kernel_still_agrees(monkeypatch):
+    """The register-resident kernel serves every shape of the path; the LDS-score kernel stays as the fallback for
+    shapes outside its instances.  Both against fp64, memory slots + key mask and geometry + per-query mask."""
+    from openviic_amd import ops
+    g = torch.Generator().manual_seed(12)
+    b, nq, nk, h, dk, m = 2, 50, 50, 8, 64, 40
+    q, k, v = (torch.randn(b, n, h * dk, generator=g) for n in (nq, nk, nk))
+    keymask = torch.rand(b, 1, 1, nk, generator=g) < 0.3
+    keymask[..., 0] = False
+    qmask = torch.rand(b, 1, nq, nk, generator=g) < 0.3
+    qmask[..., 0] = False
+    geometry = torch.rand(b, h, nq, nk, generator=g) * 2 - 0.5
+    memory = (torch.randn(1, m, h * dk, generator=g) / dk, torch.randn(1, m, h * dk, generator=g) / m, math.sqrt(dk), math.sqrt(m))
+    mem_dev = (memory[0].to(DEV), memory[1].to(DEV), memory[2], memory[3])
+    for general in ("", "1"):
+        if general:
+            monkeypatch.setenv("OVC_ATTENTION_GENERAL", "1")
+        got = ops.attention(q.to(DEV), k.to(DEV), v.to(DEV), h, mask=keymask.to(DEV), memory=mem_dev)
+        _close(got, _sdpa_ref(q, k, v, h, keymask, None, memory), what="memory, general=%r" % general)
+        got = ops.attention(q.to(DEV), k.to(DEV), v.to(DEV), h, mask=qmask.to(DEV), geometry=geometry.to(DEV))
+        _close(got, _sdpa_ref(q, k, v, h, qmask, geometry), what="geometry, general=%r" % general)
+
+
 def test_causal_mask_attention_matches_teacher_forcing_shape():
     from openviic_amd import ops
     g = torch.Generator().manual_seed(3)
