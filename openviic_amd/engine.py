@@ -60,7 +60,8 @@ class CaptionEngine:
     # objective of the tiling measurement (ovc_gemm_tune_objective): 1 = isolated latency (default); c > 1 ranks
     # tilings by the time of c co-running copies, which picks larger tiles.  Measured with 4 batches in flight:
     # +0.6 % captions/s for c = 4 (same-box A/B), up to +3.7 % for a search under the real load
-    # (tools/tiling_throughput_probe.py), while the same kernels run alone drop from 91 to 69 TFLOP/s.
+    # (round-1 probe, since removed); round 2, same box, alternating runs: c = 2 gives +2.5..3 % on 4 streams (22.0k ->
+    # 22.7k) and -6 % on the single-stream kernel-scoped GEMM rate (91.5 -> 85.6 TFLOP/s).  Either way the bits are the same.
     tune_concurrency = int(os.environ.get("OVC_TUNE_CONCURRENCY", "1"))
     # replay the decode launch sequence as a hipGraph from the third call of a shape on (OVC_GRAPH=0: plain launches)
     use_graph = os.environ.get("OVC_GRAPH", "1") != "0"

@@ -1,5 +1,5 @@
 #!/bin/bash
-# A/B timing on ONE box: the in-tree libovc.so against another build of the same ABI (tools/libovc_prev.bin),
+# A/B timing on ONE box: the in-tree libovc.so against another build of the same ABI (tools/libovc_base.bin),
 # alternating, 3 streams and 1 stream.   tools/ab_bench.sh [rounds]
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 PREV=$ROOT/tools/libovc_base.bin
