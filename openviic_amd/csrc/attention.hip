@@ -382,12 +382,11 @@ extern "C" int ovc_attention(const float* q, const float* k, const float* v, int
         }
     }
     const size_t lds_bytes = sizeof(float) * ((size_t)kQTile * kLdQK + 2 * (size_t)p.nkp * kLdQK + (size_t)kQTile * (p.nkp + 4));
-    static bool attr_set = false;
-    if (!attr_set) {
+    static std::once_flag attr_once;
+    std::call_once(attr_once, [] {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attention_mfma_kernel),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-        attr_set = true;
-    }
+    });
     hipLaunchKernelGGL(attention_mfma_kernel, dim3(b * h * p.qtiles), dim3(256), lds_bytes, ovc_hip_stream(stream), p);
     OVC_RETURN_IF_LAUNCH_FAILED();
     return OVC_OK;
@@ -730,12 +729,11 @@ int ovc_decode_cross_attention(const DecodeCrossArgs& p, int B, int h, int level
         return OVC_OK;
     }
     const size_t lds_bytes = sizeof(float) * (2 * (size_t)p.n * kLdQK + (size_t)p.width * 64 + (size_t)p.width * p.n);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static std::once_flag attr_once;
+    std::call_once(attr_once, [] {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(decode_cross_attention_lds_kernel),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
+    });
     hipLaunchKernelGGL(decode_cross_attention_lds_kernel, dim3(B, h, levels), dim3(256), lds_bytes, stream, p);
     OVC_RETURN_IF_LAUNCH_FAILED();
     return OVC_OK;
