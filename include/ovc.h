@@ -166,6 +166,10 @@ typedef struct {
     const float* word_emb;            /* decoder.word_emb.components.weight [V, d]          */
     const float* pos_emb;             /* decoder.pos_emb.weight [max_len+1, d]              */
     const float* fc;                  /* decoder.fc.weight [V, d] (no bias)                 */
+    int32_t tune_objective;           /* which GEMM tuning table the engine consults: 0 / 1 = tilings measured in
+                                         isolation, c > 1 = measured with c co-running copies (ovc_gemm_tune_objective)
+                                         -- for hosts that keep several batches in flight on different streams.
+                                         Speed only: all tilings of a K-order class give the same bits.            */
 } ovc_model;
 
 /* Sizes the engine accepts (anything else: ovc_workspace_bytes returns 0, the calls OVC_EINVAL) -- the
@@ -244,7 +248,9 @@ long ovc_gemm_tune_calls(void);        /* measurements run so far in this proces
 /* What ovc_gemm_tune minimises: the time of `copies` identical products co-running in one launch (1..8).
  * 1 (default) ranks tilings by isolated latency, which favours many small tiles; with several independent
  * batches in flight on different streams, rank with copies = that number: fewer, larger tiles then win
- * because they spend fewer CU-seconds and less L2 traffic per FLOP.  Affects later ovc_gemm_tune calls. */
+ * because they spend fewer CU-seconds and less L2 traffic per FLOP.  Each objective has its own table: the setting
+ * selects the table that later ovc_gemm_tune / ovc_gemm_tuned_get / ovc_gemm_tuned_set calls work on; which table an
+ * engine call consults is ovc_model::tune_objective. */
 int ovc_gemm_tune_objective(int copies);
 
 /* Read / preset the remembered tiling of (shape, class): lets a host persist tuning results.  get returns the

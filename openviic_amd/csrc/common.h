@@ -56,6 +56,8 @@ struct GemmArgs {
     int kchains;         // K-order class (gemm.hip): 1 (or 0) = one summation chain over k, 4 = four interleaved chains
                          // summed in chain order.  Part of the product's DEFINITION: every tiling of a class gives the
                          // same bits, so the caller fixes it per call site and no timing can change a result.
+    int objective;       // which tuning table to consult: 0 / 1 = measured in isolation, c > 1 = measured with c co-running copies
+                         // (speed only: every tiling of the class gives the same bits)
     GemmSegment seg[OVC_MAX_SEGMENTS];
 };
 

@@ -239,6 +239,7 @@ struct Engine {
 
     int gemm(GemmArgs& a) {
         a.kchains = kchains;
+        a.objective = m->tune_objective;
         if (dry) {
             const GemmShape sh{a.M, a.seg_n, a.nseg, a.K1 + a.K2, kchains, a.ksplit > 1 ? a.ksplit : 1};
             if (std::find(dry->begin(), dry->end(), sh) == dry->end()) dry->push_back(sh);
@@ -532,7 +533,7 @@ int run_decode_step(Engine& e, Workspace& w, int B, int N, int k, int t, int ret
 
 }  // namespace
 
-extern "C" int ovc_abi_version(void) { return 2; }
+extern "C" int ovc_abi_version(void) { return 3; }
 
 extern "C" const char* ovc_build_info(void) {
     return "libovc gfx950 (CDNA4) fp32: v_mfma_f32_32x32x2_f32 GEMM + attention, HIP " __DATE__;

@@ -431,7 +431,7 @@ std::atomic<int> g_forced_tiling{-1};
 
 // Shapes measured by ovc_gemm_tune: (M, seg_n, nseg, K, kchains, ksplit) -> fastest tiling of that class on this
 // device.  Guarded by g_tuned_mutex (the engine may be driven from several host threads).
-struct TunedShape { int M, seg_n, nseg, K, kchains, ksplit, tiling; };
+struct TunedShape { int M, seg_n, nseg, K, kchains, ksplit, objective, tiling; };
 std::vector<TunedShape> g_tuned;
 std::mutex g_tuned_mutex;
 std::atomic<int> g_tune_copies{1};      // objective of ovc_gemm_tune: 1 = isolated latency, c > 1 = c co-running copies
@@ -440,12 +440,14 @@ std::atomic<long> g_tune_calls{0};      // measurements actually run (tests asse
 // Exact entry, or (near = true) the entry of the same product whose M is closest within a factor of two: the best
 // tiling moves slowly with M, and every tiling of a class gives the same bits, so borrowing a neighbour's choice
 // costs at most a little speed.  Batches whose region count varies (M = B*N) then never wait for a tuning run.
-int tuned_lookup(int M, int seg_n, int nseg, int K, int kchains, int ksplit, bool near) {
+// `objective` = how many identical products co-ran when the entry was measured (ovc_gemm_tune_objective): a caller that
+// keeps several batches in flight looks up the table measured that way, one that decodes alone the isolated one.
+int tuned_lookup(int M, int seg_n, int nseg, int K, int kchains, int ksplit, int objective, bool near) {
     std::lock_guard<std::mutex> lock(g_tuned_mutex);
     int best = -1;
     double best_ratio = 2.0;
     for (const TunedShape& t : g_tuned) {
-        if (t.seg_n != seg_n || t.nseg != nseg || t.K != K || t.kchains != kchains || t.ksplit != ksplit) continue;
+        if (t.seg_n != seg_n || t.nseg != nseg || t.K != K || t.kchains != kchains || t.ksplit != ksplit || t.objective != objective) continue;
         if (t.M == M) return t.tiling;
         if (!near) continue;
         const double ratio = t.M > M ? (double)t.M / M : (double)M / t.M;
@@ -503,7 +505,10 @@ int ovc_gemm_pick_tiling(const GemmArgs& a, const GemmLaunchOpts& opts) {
     if (opts.forced_tiling >= 0) return opts.forced_tiling < kNumTilings && tiling_fits(a, opts.forced_tiling) ? opts.forced_tiling : -1;
     const int forced = g_forced_tiling.load();
     if (forced >= 0 && tiling_fits(a, forced)) return forced;
-    const int tuned = tuned_lookup(a.M, a.seg_n, a.nseg, a.K1 + a.K2, args_chains(a), a.ksplit > 1 ? a.ksplit : 1, true);
+    const int objective = a.objective > 1 ? a.objective : 1;
+    int tuned = tuned_lookup(a.M, a.seg_n, a.nseg, a.K1 + a.K2, args_chains(a), a.ksplit > 1 ? a.ksplit : 1, objective, true);
+    if (tuned < 0 && objective > 1)     // nothing measured under that load: the isolated entry is still better than the cost model
+        tuned = tuned_lookup(a.M, a.seg_n, a.nseg, a.K1 + a.K2, args_chains(a), a.ksplit > 1 ? a.ksplit : 1, 1, true);
     if (tuned >= 0 && tiling_fits(a, tuned)) return tuned;
     double best = 1e300;
     int pick = -1;
@@ -564,7 +569,8 @@ extern "C" int ovc_gemm_tune(int M, int seg_n, int nseg, int K, int kchains, int
     float* W = A + ((na + 3) & ~(size_t)3);
     float* C = W + ((nw + 3) & ~(size_t)3);
     if ((size_t)(C - A) + (size_t)ksplit * nc > scratch_bytes / sizeof(float)) return OVC_EWORKSPACE;
-    if (tuned_lookup(M, seg_n, nseg, K, kchains, ksplit, false) >= 0) return OVC_OK;
+    const int objective = g_tune_copies.load();
+    if (tuned_lookup(M, seg_n, nseg, K, kchains, ksplit, objective, false) >= 0) return OVC_OK;
     GemmArgs a{};
     a.A1 = A; a.lda1 = K; a.K1 = K; a.M = M; a.seg_n = seg_n; a.nseg = nseg; a.ldc = seg_n; a.kchains = kchains;
     if (ksplit > 1) { a.ksplit = ksplit; a.part_stride = (long)nc; }
@@ -575,7 +581,7 @@ extern "C" int ovc_gemm_tune(int M, int seg_n, int nseg, int K, int kchains, int
     int rc = OVC_OK, best = -1;
     float best_ms = 1e30f;
     GemmLaunchOpts opts{};
-    opts.copies = g_tune_copies.load();
+    opts.copies = objective;
     for (int t = 0; t < kNumTilings && rc == OVC_OK; ++t) {
         if (!tiling_fits(a, t)) continue;
         opts.forced_tiling = t;
@@ -592,7 +598,7 @@ extern "C" int ovc_gemm_tune(int M, int seg_n, int nseg, int K, int kchains, int
     if (rc != OVC_OK) return rc;
     if (best >= 0) {
         std::lock_guard<std::mutex> lock(g_tuned_mutex);
-        g_tuned.push_back(TunedShape{M, seg_n, nseg, K, kchains, ksplit, best});
+        g_tuned.push_back(TunedShape{M, seg_n, nseg, K, kchains, ksplit, objective, best});
     }
     return OVC_OK;
 }
@@ -608,7 +614,7 @@ extern "C" long ovc_gemm_tune_calls(void) { return g_tune_calls.load(); }
 // Remembered tiling of a shape: -1 = nothing usable.  near != 0 also accepts the entry of the same product with the
 // closest M within a factor of two (what the launch path itself falls back to).
 extern "C" int ovc_gemm_tuned_get(int M, int seg_n, int nseg, int K, int kchains, int ksplit, int near) {
-    return tuned_lookup(M, seg_n, nseg, K, kchains == 4 ? 4 : 1, ksplit > 1 ? ksplit : 1, near != 0);
+    return tuned_lookup(M, seg_n, nseg, K, kchains == 4 ? 4 : 1, ksplit > 1 ? ksplit : 1, g_tune_copies.load(), near != 0);
 }
 
 extern "C" int ovc_gemm_tuned_set(int M, int seg_n, int nseg, int K, int kchains, int ksplit, int tiling) {
@@ -618,10 +624,11 @@ extern "C" int ovc_gemm_tuned_set(int M, int seg_n, int nseg, int K, int kchains
     a.M = M; a.seg_n = seg_n; a.nseg = nseg; a.K1 = K; a.kchains = kchains; a.ksplit = ksplit;
     if (ksplit > 1 && (nseg != 1 || K % (ksplit * 32))) return OVC_EINVAL;
     if (!tiling_fits(a, tiling)) return OVC_EINVAL;           // wrong class, tile straddling a segment, slice not a whole K tile
-    const TunedShape entry{M, seg_n, nseg, K, kchains, ksplit, tiling};
+    const int objective = g_tune_copies.load();
+    const TunedShape entry{M, seg_n, nseg, K, kchains, ksplit, objective, tiling};
     std::lock_guard<std::mutex> lock(g_tuned_mutex);
     for (TunedShape& t : g_tuned)
-        if (t.M == M && t.seg_n == seg_n && t.nseg == nseg && t.K == K && t.kchains == kchains && t.ksplit == ksplit) { t = entry; return OVC_OK; }
+        if (t.M == M && t.seg_n == seg_n && t.nseg == nseg && t.K == K && t.kchains == kchains && t.ksplit == ksplit && t.objective == objective) { t = entry; return OVC_OK; }
     g_tuned.push_back(entry);
     return OVC_OK;
 }

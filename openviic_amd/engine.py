@@ -14,11 +14,16 @@ Numerics never depend on a timing: the order in which every GEMM sums over K is 
 import ctypes
 import json
 import os
+import threading
 
 import torch
 
 from . import native
 from .native import check
+
+
+# ovc_gemm_tune_objective selects the table the following tune / get / set calls act on: one such sequence at a time
+_TUNE_LOCK = threading.Lock()
 
 
 def _p(t):
@@ -69,9 +74,11 @@ class CaptionEngine:
     # identical; with ragged real-data batches a bucket of 8 or 16 bounds the number of distinct shapes (graphs).
     region_bucket = int(os.environ.get("OVC_REGION_BUCKET", "1"))
 
-    def __init__(self, model):
+    def __init__(self, model, tune_concurrency=None):
         self.lib = native.load()
         self.model = model
+        if tune_concurrency is not None:          # per engine: e.g. 2 for a host that alternates batches over 3-4 streams
+            self.tune_concurrency = int(tune_concurrency)
         self._keep = []          # tensors created here whose storage the pointer table references
         self._fc_g = None
         self.desc = self._describe(model)
@@ -128,6 +135,7 @@ class CaptionEngine:
         d.word_emb = _p(dec.word_emb.components.weight.detach())
         d.pos_emb = _p(dec.pos_emb.weight.detach())
         d.fc = _p(dec.fc.weight.detach())
+        d.tune_objective = max(1, min(8, int(self.tune_concurrency)))
         return d
 
     def _refresh_derived(self):
@@ -156,11 +164,18 @@ class CaptionEngine:
         fastest (synchronises; ~0.2 s).  Speed only: all tilings of a class give the same bits.  Shapes for which the
         library already holds an entry with M within a factor of two (another region count or batch size) are not
         measured again, so batches with varying N never wait here after the first one."""
+        objective = int(self.desc.tune_objective)
         key = (B, N, k)
         if key in self._tuned:
             return
+        with _TUNE_LOCK:
+            self._tune_locked(B, N, k, objective)
+        self._tuned.add(key)
+
+    def _tune_locked(self, B, N, k, objective):
         shapes = self.gemm_shapes(B, N, k)
-        objective = max(1, min(8, int(self.tune_concurrency)))
+        # each objective has its own table in the library; the setting selects the one tuned_get / tune / tuned_set act on
+        check(self.lib.ovc_gemm_tune_objective(objective), "ovc_gemm_tune_objective")
         cache_path = os.environ.get("OVC_TUNE_CACHE")       # optional json: {"M,seg_n,nseg,K,kchains,ksplit@objective": tiling}
         cache = {}
         if cache_path and os.path.exists(cache_path):
@@ -172,7 +187,6 @@ class CaptionEngine:
                     self.lib.ovc_gemm_tuned_set(*shape, int(cache[name]))
         todo = [sh for sh in shapes if self.lib.ovc_gemm_tuned_get(*sh, 1) < 0]
         if todo:
-            check(self.lib.ovc_gemm_tune_objective(objective), "ovc_gemm_tune_objective")
             # operands + output (K-split shapes: one partial output per slice)
             need = max(4 * (m * kk + sn * ns * kk + m * sn * ns * ks) + 256 for m, sn, ns, kk, _, ks in todo)
             scratch = torch.empty(need // 4 + 16, dtype=torch.float32, device=self.device).normal_()
@@ -180,7 +194,6 @@ class CaptionEngine:
                 check(self.lib.ovc_gemm_tune(*sh, scratch.data_ptr(), scratch.numel() * 4, native.stream_handle()),
                       "ovc_gemm_tune{}".format(sh))
             torch.cuda.current_stream().synchronize()
-        self._tuned.add(key)
         if cache_path and todo:
             for shape in shapes:
                 t = self.lib.ovc_gemm_tuned_get(*shape, 0)
