@@ -170,6 +170,13 @@ typedef struct {
                                          isolation, c > 1 = measured with c co-running copies (ovc_gemm_tune_objective)
                                          -- for hosts that keep several batches in flight on different streams.
                                          Speed only: all tilings of a K-order class give the same bits.            */
+    int32_t precision;                /* 0 = fp32 MFMA everywhere: the parity mode and the only one the headline numbers
+                                         use.  1 / 2 / 3 = OPT-IN split precision: every GEMM of the engine cuts its fp32
+                                         operands into that many bf16 planes and contracts them on the 16-bit matrix path
+                                         with fp32 accumulation (1, 3 or 6 plane products: "bf16", "bf16x3", "bf16x6";
+                                         K-order classes 101..103).  fp32 in, fp32 out, attention / LayerNorm / selection
+                                         unchanged; results differ from mode 0 in the low-order bits (3), at ~1e-5 (2)
+                                         or ~1e-2 (1) relative -- see DESIGN.md for measured token-id agreement.       */
 } ovc_model;
 
 /* Sizes the engine accepts (anything else: ovc_workspace_bytes returns 0, the calls OVC_EINVAL) -- the
@@ -232,6 +239,8 @@ const char* ovc_profile_kernel_name(int tiling);   /* "" past the last tiling */
  *   kchains = 4   four interleaved chains summed in chain order (the engine's M = B*beam decode-step products);
  *   ksplit  = s   K cut into s contiguous slices whose raw partial products the consuming LayerNorm sums in
  *                 slice order (engine only; a fixed function of K).
+ *   kchains = 101 / 102 / 103   the opt-in split-precision classes (ovc_model::precision = 1 / 2 / 3): one chain of
+ *                 16-deep bf16 MFMA steps, plane products in a fixed order.
  * All tilings of one class produce bit-identical results, so token ids do not depend on the batch size, on the
  * GPU box or on what a timing run picked (the reference is deterministic on CPU: torch.sort path,
  * models/modules/beam_search.py:36-39).

@@ -84,6 +84,8 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return base + (bid >> 3);
 }
 
+#include "gemm_split.h"   // gemm_bf16_split: the opt-in split-precision classes (bf16 planes on the 16-bit matrix path)
+
 // Registers are capped where residency matters: the M = 1280 decode products come as 1280 workgroups of 32x64 tiles,
 // five per CU -- with more than 96 registers only four are resident and the fifth runs as a second round (35 vs 28 us).
 template <int BM, int BN, int BK, int NC>
@@ -365,6 +367,25 @@ __global__ __launch_bounds__(256, (min_waves_per_simd<BM, BN, BK, NC>())) void g
     }
 }
 
+// tile order shared by both kernels: super-rows of M tiles when the A panel exceeds an L2, else the 2-D XCD split with
+// the least Infinity-Cache traffic  pn * |A| + pm * |W|
+void tile_order(const GemmArgs& a, int tiles_m, int tiles_n, int* group_m, int* xcd_pm) {
+    const size_t a_bytes = sizeof(float) * (size_t)a.M * (a.K1 + a.K2);
+    *group_m = a_bytes <= (size_t)3 << 20 ? tiles_m : (tiles_m < 8 ? tiles_m : 8);
+    *xcd_pm = 0;
+    const int slices = a.ksplit > 1 ? a.ksplit : 1;
+    if (a_bytes / slices <= (size_t)3 << 20) {
+        const size_t w_bytes = sizeof(float) * (size_t)a.seg_n * a.nseg * (a.K1 + a.K2);
+        const int tiles_n_all = tiles_n * a.nseg;
+        size_t best = 8 * a_bytes + w_bytes;
+        for (int pm = 2; pm <= 8; pm *= 2) {
+            if (tiles_m % pm || tiles_n_all % (8 / pm)) continue;
+            const size_t cost = (size_t)(8 / pm) * a_bytes + (size_t)pm * w_bytes;
+            if (cost < best) { best = cost; *xcd_pm = pm; }
+        }
+    }
+}
+
 template <int BM, int BN, int WM, int WN, int WK, int BK, int NC>
 int launch_config(const GemmArgs& a, hipStream_t stream, const GemmLaunchOpts& opts) {
     using Cfg = TileConfig<BM, BN, WM, WN, WK, BK, NC>;
@@ -377,22 +398,9 @@ int launch_config(const GemmArgs& a, hipStream_t stream, const GemmLaunchOpts& o
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f32_mfma<BM, BN, WM, WN, WK, BK, NC>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     });
-    // A panel larger than ~3 MB cannot stay in a 4 MB L2: sweep it in super-rows of 8 M tiles
-    const size_t a_bytes = sizeof(float) * (size_t)a.M * (a.K1 + a.K2);
-    const int group_m = a_bytes <= (size_t)3 << 20 ? tiles_m : (tiles_m < 8 ? tiles_m : 8);
-    // operands that fit the L2s: 2-D XCD split with the least Infinity-Cache traffic  pn * |A| + pm * |W|
-    int xcd_pm = 0;
+    int group_m, xcd_pm;
+    tile_order(a, tiles_m, tiles_n, &group_m, &xcd_pm);
     const int slices = a.ksplit > 1 ? a.ksplit : 1;         // K slices run one after the other (gridDim.y is the slow index)
-    if (a_bytes / slices <= (size_t)3 << 20) {
-        const size_t w_bytes = sizeof(float) * (size_t)a.seg_n * a.nseg * (a.K1 + a.K2);
-        const int tiles_n_all = tiles_n * a.nseg;
-        size_t best = 8 * a_bytes + w_bytes;                 // a split along N only (pm = 1): the plain tile order
-        for (int pm = 2; pm <= 8; pm *= 2) {
-            if (tiles_m % pm || tiles_n_all % (8 / pm)) continue;
-            const size_t cost = (size_t)(8 / pm) * a_bytes + (size_t)pm * w_bytes;
-            if (cost < best) { best = cost; xcd_pm = pm; }
-        }
-    }
     // opts.copies (tuner only): gridDim.z identical copies of the product in one launch (the kernel ignores
     // blockIdx.z), a proxy for "this many batches in flight" that needs no extra streams.
     const dim3 grid3(grid, slices, opts.copies > 1 ? opts.copies : 1);
@@ -405,8 +413,34 @@ int launch_config(const GemmArgs& a, hipStream_t stream, const GemmLaunchOpts& o
     return OVC_OK;
 }
 
-// bm, bn, wm, wn, wk, bk, nc; chains = wk * nc is the K-order class the instance belongs to
-struct TilingInfo { int bm, bn, wm, wn, wk, bk, nc; };
+template <int BM, int BN, int WM, int WN, int BK, int P>
+int launch_split_config(const GemmArgs& a, hipStream_t stream, const GemmLaunchOpts& opts) {
+    using Cfg = SplitConfig<BM, BN, WM, WN, BK, P>;
+    const int tiles_m = (a.M + BM - 1) / BM;
+    const int tiles_n = (a.seg_n + BN - 1) / BN;
+    const int grid = tiles_m * tiles_n * a.nseg;
+    const size_t lds_bytes = Cfg::kLdsBytes;
+    static std::once_flag attr_once;
+    std::call_once(attr_once, [&] {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_split<BM, BN, WM, WN, BK, P>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    });
+    int group_m, xcd_pm;
+    tile_order(a, tiles_m, tiles_n, &group_m, &xcd_pm);
+    const dim3 grid3(grid, a.ksplit > 1 ? a.ksplit : 1, opts.copies > 1 ? opts.copies : 1);
+    if (opts.start && opts.stop)
+        hipExtLaunchKernelGGL((gemm_bf16_split<BM, BN, WM, WN, BK, P>), grid3, dim3(256), (uint32_t)lds_bytes, stream,
+                              opts.start, opts.stop, 0, a, tiles_m, tiles_n, group_m, xcd_pm);
+    else
+        hipLaunchKernelGGL((gemm_bf16_split<BM, BN, WM, WN, BK, P>), grid3, dim3(256), lds_bytes, stream, a, tiles_m, tiles_n, group_m, xcd_pm);
+    OVC_RETURN_IF_LAUNCH_FAILED();
+    return OVC_OK;
+}
+
+// bm, bn, wm, wn, wk, bk, nc, planes.  fp32 tilings (planes = 0): chains = wk * nc is the K-order class the instance
+// belongs to; split-precision tilings (planes = 1..3): class 100 + planes (kSplitClass).
+struct TilingInfo { int bm, bn, wm, wn, wk, bk, nc, planes; };
+constexpr int kSplitClass = 100;
 #define OVC_TILINGS(X)                                                                                   \
     /* one chain (kchains = 1) */                                                                        \
     X(0, 128, 128, 2, 2, 1, 32, 1) X(1, 64, 128, 2, 2, 1, 32, 1) X(2, 128, 64, 2, 2, 1, 32, 1)          \
@@ -419,11 +453,20 @@ struct TilingInfo { int bm, bn, wm, wn, wk, bk, nc; };
     /* epilogues then overlap other workgroups' MFMA (the fixed cost per round of workgroups drops by a third)   */ \
     X(15, 64, 64, 2, 2, 1, 16, 1) X(16, 128, 128, 2, 2, 1, 16, 1)
 //  (K tiles of 128 were tried for the small tilings: slower -- 15.6 vs 12.2 us on 1280x512x512)
-#define OVC_TILING_INFO(id, bm, bn, wm, wn, wk, bk, nc) {bm, bn, wm, wn, wk, bk, nc},
-constexpr TilingInfo kTilings[] = {OVC_TILINGS(OVC_TILING_INFO)};
+// split-precision tilings: id, bm, bn, wm, wn, bk, planes (one chain each; ids follow the fp32 ones)
+#define OVC_SPLIT_SHAPES(X, first, planes)                                                                \
+    X(first + 0, 128, 128, 2, 2, 32, planes) X(first + 1, 64, 128, 2, 2, 32, planes) X(first + 2, 128, 64, 2, 2, 32, planes) \
+    X(first + 3, 64, 64, 2, 2, 32, planes) X(first + 4, 32, 128, 1, 4, 32, planes)
+#define OVC_SPLIT_TILINGS(X) OVC_SPLIT_SHAPES(X, 17, 1) OVC_SPLIT_SHAPES(X, 22, 2) OVC_SPLIT_SHAPES(X, 27, 3)
+#define OVC_TILING_INFO(id, bm, bn, wm, wn, wk, bk, nc) {bm, bn, wm, wn, wk, bk, nc, 0},
+#define OVC_SPLIT_INFO(id, bm, bn, wm, wn, bk, planes) {bm, bn, wm, wn, 1, bk, 1, planes},
+constexpr TilingInfo kTilings[] = {OVC_TILINGS(OVC_TILING_INFO) OVC_SPLIT_TILINGS(OVC_SPLIT_INFO)};
 #undef OVC_TILING_INFO
+#undef OVC_SPLIT_INFO
 constexpr int kNumTilings = sizeof(kTilings) / sizeof(kTilings[0]);
-inline int tiling_chains(int t) { return kTilings[t].wk * kTilings[t].nc; }
+static_assert(kNumTilings == 32, "tiling ids: 17 fp32 + 15 split-precision");
+inline int tiling_chains(int t) { return kTilings[t].planes ? kSplitClass + kTilings[t].planes : kTilings[t].wk * kTilings[t].nc; }
+inline bool class_ok(int c) { return c == 1 || c == 4 || (c > kSplitClass && c <= kSplitClass + 3); }
 
 // Debug hook (ovc_debug_force_gemm_tiling): applies to every launch that does not carry its own
 // GemmLaunchOpts::forced_tiling and whose class matches; not for use while other threads decode.
@@ -465,14 +508,16 @@ double tiling_cost(const GemmArgs& a, const TilingInfo& t) {
     const int K = a.K1 + a.K2;
     const long wgs = (long)((a.M + t.bm - 1) / t.bm) * ((a.seg_n + t.bn - 1) / t.bn) * a.nseg;
     const double per_cu = (double)((wgs + 255) / 256);                       // workgroups on the busiest CU
-    const double mfma_per_wave = (double)(t.bm / 32) * (t.bn / 32) * (K / 2.0) / 4.0;
+    // split precision: planes (planes + 1) / 2 bf16 MFMAs of 32 cycles per 16-deep step against one fp32 MFMA of 64 per 2
+    const double k_units = t.planes ? K / 16.0 * (t.planes * (t.planes + 1) / 2) * 0.5 : K / 2.0;
+    const double mfma_per_wave = (double)(t.bm / 32) * (t.bn / 32) * k_units / 4.0;
     const double overhead = 48.0 + (t.bk >= 64 ? 1e9 : 0.0);                 // BK=64 tilings: only when measured or forced
     const double bytes_per_flop = 2.0 * (t.bm + t.bn) / (double)(t.bm * t.bn);   // operand floats per MAC
     const double bw_penalty = 1.0 + 4.0 * bytes_per_flop;                    // 128x128: 1.06, 32x32: 1.5
     return per_cu * (mfma_per_wave * bw_penalty + overhead);
 }
 
-int args_chains(const GemmArgs& a) { return a.kchains == 4 ? 4 : 1; }
+int args_chains(const GemmArgs& a) { return a.kchains > kSplitClass ? a.kchains : (a.kchains == 4 ? 4 : 1); }
 
 // A tiling fits a problem when it belongs to the problem's K-order class, no tile straddles two N segments and the
 // A1|A2 seam / the K slices fall on K-tile boundaries.
@@ -494,8 +539,10 @@ extern "C" int ovc_debug_force_gemm_tiling(int tiling) {
 
 const char* ovc_gemm_tiling_name(int tiling) {
 #define OVC_TILING_NAME(id, bm, bn, wm, wn, wk, bk, nc) "gemm_f32_mfma<" #bm ", " #bn ", " #wm ", " #wn ", " #wk ", " #bk ", " #nc ">",
-    static const char* names[] = {OVC_TILINGS(OVC_TILING_NAME)};
+#define OVC_SPLIT_NAME(id, bm, bn, wm, wn, bk, planes) "gemm_bf16_split<" #bm ", " #bn ", " #wm ", " #wn ", " #bk ", " #planes ">",
+    static const char* names[] = {OVC_TILINGS(OVC_TILING_NAME) OVC_SPLIT_TILINGS(OVC_SPLIT_NAME)};
 #undef OVC_TILING_NAME
+#undef OVC_SPLIT_NAME
     return tiling >= 0 && tiling < kNumTilings ? names[tiling] : "";
 }
 
@@ -523,7 +570,7 @@ int ovc_gemm_pick_tiling(const GemmArgs& a, const GemmLaunchOpts& opts) {
 int ovc_gemm_launch(const GemmArgs& a, hipStream_t stream, const GemmLaunchOpts& opts) {
     const int K = a.K1 + a.K2;
     if (a.M <= 0 || a.seg_n <= 0 || a.nseg <= 0 || a.nseg > OVC_MAX_SEGMENTS || K <= 0) return OVC_EINVAL;
-    if (a.kchains != 0 && a.kchains != 1 && a.kchains != 4) return OVC_EINVAL;
+    if (a.kchains != 0 && !class_ok(a.kchains)) return OVC_EINVAL;
     if ((a.K1 & 3) || (a.K2 & 3) || (a.lda1 & 3) || (a.K2 && (a.lda2 & 3))) return OVC_EINVAL;
     if (!ovc_aligned16(a.A1) || (a.K2 && !a.A2 && !a.seg[0].A2) || (a.A2 && !ovc_aligned16(a.A2))) return OVC_EINVAL;
     for (int s = 0; s < a.nseg; ++s)
@@ -549,8 +596,11 @@ int ovc_gemm_launch(const GemmArgs& a, hipStream_t stream, const GemmLaunchOpts&
     const int pick = ovc_gemm_pick_tiling(a, opts);
     switch (pick) {
 #define OVC_TILING_CASE(id, bm, bn, wm, wn, wk, bk, nc) case id: return launch_config<bm, bn, wm, wn, wk, bk, nc>(a, stream, opts);
+#define OVC_SPLIT_CASE(id, bm, bn, wm, wn, bk, planes) case id: return launch_split_config<bm, bn, wm, wn, bk, planes>(a, stream, opts);
         OVC_TILINGS(OVC_TILING_CASE)
+        OVC_SPLIT_TILINGS(OVC_SPLIT_CASE)
 #undef OVC_TILING_CASE
+#undef OVC_SPLIT_CASE
         default: return OVC_EINVAL;
     }
 }
@@ -561,7 +611,7 @@ int ovc_gemm_launch(const GemmArgs& a, hipStream_t stream, const GemmLaunchOpts&
 extern "C" int ovc_gemm_tune(int M, int seg_n, int nseg, int K, int kchains, int ksplit, void* scratch, size_t scratch_bytes,
                              ovc_stream stream) {
     if (M <= 0 || seg_n <= 0 || nseg <= 0 || nseg > OVC_MAX_SEGMENTS || K <= 0 || (K & 3)) return OVC_EINVAL;
-    if ((kchains != 1 && kchains != 4) || ksplit < 1 || ksplit > kMaxKSplit || (ksplit > 1 && (nseg != 1 || K % (ksplit * 32)))) return OVC_EINVAL;
+    if (!class_ok(kchains) || ksplit < 1 || ksplit > kMaxKSplit || (ksplit > 1 && (nseg != 1 || K % (ksplit * 32)))) return OVC_EINVAL;
     const size_t na = (size_t)M * K, nw = (size_t)seg_n * nseg * K, nc = (size_t)M * seg_n * nseg;
     if (!scratch || !ovc_aligned16(scratch)) return OVC_EWORKSPACE;
     if (nseg > 1 && seg_n % 64) return OVC_EINVAL;
@@ -614,11 +664,11 @@ extern "C" long ovc_gemm_tune_calls(void) { return g_tune_calls.load(); }
 // Remembered tiling of a shape: -1 = nothing usable.  near != 0 also accepts the entry of the same product with the
 // closest M within a factor of two (what the launch path itself falls back to).
 extern "C" int ovc_gemm_tuned_get(int M, int seg_n, int nseg, int K, int kchains, int ksplit, int near) {
-    return tuned_lookup(M, seg_n, nseg, K, kchains == 4 ? 4 : 1, ksplit > 1 ? ksplit : 1, g_tune_copies.load(), near != 0);
+    return tuned_lookup(M, seg_n, nseg, K, class_ok(kchains) ? kchains : 1, ksplit > 1 ? ksplit : 1, g_tune_copies.load(), near != 0);
 }
 
 extern "C" int ovc_gemm_tuned_set(int M, int seg_n, int nseg, int K, int kchains, int ksplit, int tiling) {
-    if (tiling < 0 || tiling >= kNumTilings || (kchains != 1 && kchains != 4) || ksplit < 1 || ksplit > kMaxKSplit) return OVC_EINVAL;
+    if (tiling < 0 || tiling >= kNumTilings || !class_ok(kchains) || ksplit < 1 || ksplit > kMaxKSplit) return OVC_EINVAL;
     if (M <= 0 || seg_n <= 0 || nseg <= 0 || nseg > OVC_MAX_SEGMENTS || K <= 0) return OVC_EINVAL;
     GemmArgs a{};
     a.M = M; a.seg_n = seg_n; a.nseg = nseg; a.K1 = K; a.kchains = kchains; a.ksplit = ksplit;

@@ -1,0 +1,279 @@
+// Split-precision GEMM (included by gemm.hip inside its anonymous namespace): the same product
+//     C[M,N] = act([A1|A2] . W^T + bias) + R      on fp32 operands in HBM, fp32 result,
+// with the contraction on the 16-bit matrix path (v_mfma_f32_32x32x16_bf16, 16x the fp32 MFMA rate) and fp32 accumulation.
+// NOT the parity mode: an opt-in (ovc_model::precision), measured and reported separately from the fp32 headline.
+//
+// Each fp32 operand element x is cut into P bf16 "planes" while its tile is staged into LDS:
+//     p0 = bf16(x), p1 = bf16(x - p0), p2 = bf16(x - p0 - p1)            (round to nearest even, residuals exact in fp32)
+// and the product is assembled from the plane products whose weight matters:
+//     P = 1   a0 b0                                   bf16 inputs:  8 mantissa bits per operand (error ~ 2^-9 per product)
+//     P = 2   a0 b0 + a0 b1 + a1 b0                   3 products:  16 bits per operand (~ 2^-17)
+//     P = 3   ... + a0 b2 + a1 b1 + a2 b0             6 products:  24 bits, the dropped terms are below fp32's own rounding
+// The small terms are accumulated first.  One summation chain over k per output (16-deep MFMA steps in order, products
+// in the fixed order above), whatever the tiling: all tilings of one P give the same bits, so the tuner may pick freely,
+// exactly as inside the fp32 K-order classes (gemm.hip).
+//
+// LDS holds bf16 planes: tile[plane][row][k] with rows padded to BK + 8 halves (80 bytes: 20 r mod 64 puts any 16 rows
+// distinct mod 16 on 16 distinct 4-bank slots, which is what one ds_read_b128 lane group touches).  Operand fragment of
+// the 32x32x16 MFMA: lane l holds row l & 31, k = 8 (l >> 5) .. + 7 -- one ds_read_b128 per plane and k step; A and B use
+// the same lane <-> k map, so every k is summed exactly once.
+// kBufs = 2: double-buffered tiles, one barrier per K tile; kBufs = 1 (large tiles at P = 3, where two buffers would leave
+// one workgroup per CU): the next tile waits in registers and is converted + written after a second barrier.
+#pragma once
+
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+template <int BM, int BN, int WM, int WN, int BK, int P>
+struct SplitConfig {
+    static constexpr int LDT = BK + 8;                          // padded LDS row stride (halves)
+    static constexpr int kWaveM = BM / WM, kWaveN = BN / WN;
+    static constexpr int TM = kWaveM / 32, TN = kWaveN / 32;
+    static constexpr int kLoadA = BM * (BK / 4) / 256;          // float4 per thread per tile
+    static constexpr int kLoadB = BN * (BK / 4) / 256;
+    static constexpr int kBufHalves = (BM + BN) * P * LDT;      // one buffer: A planes then B planes
+    static constexpr int kBufs = 2 * kBufHalves * 2 <= 80 * 1024 ? 2 : 1;
+    static constexpr int kLdsBytes = kBufs * kBufHalves * 2;
+    static constexpr int kProducts = P * (P + 1) / 2;
+    static_assert(WM * WN == 4, "four waves per workgroup");
+    static_assert(BK % 16 == 0, "a K tile holds whole 16-deep MFMA steps");
+    static_assert(kWaveM % 32 == 0 && kWaveN % 32 == 0, "wave tile must be a multiple of 32x32");
+    static_assert(kLoadA >= 1 && kLoadB >= 1, "tile too small for 256 loader threads");
+    static_assert(P >= 1 && P <= 3, "one, two or three bf16 planes");
+};
+
+// Two neighbouring elements -> P packed bf16 pairs (element 0 in the low half).
+template <int P>
+__device__ __forceinline__ void split_pair(float a, float b, unsigned int (&out)[P]) {
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        const unsigned int pk = __builtin_bit_cast(unsigned int, __builtin_convertvector((f32x2{a, b}), bf16x2));
+        out[p] = pk;
+        if (p + 1 < P) {
+            a -= __builtin_bit_cast(float, pk << 16);
+            b -= __builtin_bit_cast(float, pk & 0xffff0000u);
+        }
+    }
+}
+
+template <int BM, int BN, int WM, int WN, int BK, int P>
+__global__ __launch_bounds__(256) void gemm_bf16_split(GemmArgs p, int tiles_m, int tiles_n_per_seg, int group_m, int xcd_pm) {
+    using Cfg = SplitConfig<BM, BN, WM, WN, BK, P>;
+    constexpr int LDT = Cfg::LDT;
+    constexpr int kVecPerRow = BK / 4;
+    constexpr int kRowsPerPass = 256 / kVecPerRow;
+    extern __shared__ __attribute__((aligned(16))) __bf16 lds16[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+
+    // tile order: as gemm_f32_mfma (contiguous chunk per XCD; super-rows or a 2-D split chosen by the host)
+    const int nwg = gridDim.x;
+    const int tile = xcd_remap(blockIdx.x, nwg);
+    const int tiles_n_all = nwg / tiles_m;
+    int tile_m, tile_n_all;
+    if (xcd_pm > 0) {
+        const int per_chunk = nwg >> 3, chunk = tile / per_chunk, j = tile - chunk * per_chunk;
+        const int sub_m = tiles_m / xcd_pm, cm = chunk % xcd_pm, cn = chunk / xcd_pm;
+        const int sub_n = tiles_n_all / (8 / xcd_pm);
+        tile_m = cm * sub_m + j % sub_m;
+        tile_n_all = cn * sub_n + j / sub_m;
+    } else {
+        const int group_size = group_m * tiles_n_all;
+        const int group = tile / group_size;
+        const int first_m = group * group_m;
+        const int gm = min(group_m, tiles_m - first_m);
+        const int in_group = tile - group * group_size;
+        tile_n_all = in_group / gm;
+        tile_m = first_m + (in_group - tile_n_all * gm);
+    }
+    const int seg = tile_n_all / tiles_n_per_seg;
+    const int tile_n = tile_n_all - seg * tiles_n_per_seg;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    const float* __restrict__ W = p.seg[seg].W;
+    const int K = p.K1 + p.K2;
+    const int kslice = gridDim.y > 1 ? K / (int)gridDim.y : K;
+    const int kbase = (int)blockIdx.y * kslice;
+    const int nkt = (kslice + BK - 1) / BK;
+
+    f32x4 stage_a[Cfg::kLoadA], stage_b[Cfg::kLoadB];
+    const bool k_tail = (K % BK) != 0 || (p.K1 % BK) != 0;   // uniform; false for every real shape
+    bool a_ok = true, w_ok = true;
+
+    const __amdgpu_buffer_rsrc_t rsrc_a1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.A1), 0, p.M * p.lda1 * 4, 0x00020000);
+    const float* a2 = p.seg[seg].A2 ? p.seg[seg].A2 : p.A2;
+    const __amdgpu_buffer_rsrc_t rsrc_a2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.K2 ? a2 : p.A1), 0,
+                                                                              p.K2 ? p.M * p.lda2 * 4 : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(W), 0, p.seg_n * K * 4, 0x00020000);
+    int off_a1[Cfg::kLoadA], off_a2[Cfg::kLoadA], off_w[Cfg::kLoadB];
+    const int kq = tid % kVecPerRow;
+    {
+#pragma unroll
+        for (int i = 0; i < Cfg::kLoadA; ++i) {
+            const int row = m0 + tid / kVecPerRow + i * kRowsPerPass;
+            off_a1[i] = (row * p.lda1 + kq * 4) * 4;
+            off_a2[i] = (row * p.lda2 + kq * 4) * 4;
+        }
+#pragma unroll
+        for (int i = 0; i < Cfg::kLoadB; ++i) off_w[i] = ((n0 + tid / kVecPerRow + i * kRowsPerPass) * K + kq * 4) * 4;
+    }
+    auto load_tile = [&](int kt) {
+        const int k0 = kbase + kt * BK;
+        const bool second = k0 >= p.K1;
+        if (k_tail) {
+            a_ok = (second ? k0 - p.K1 : k0) + kq * 4 < (second ? p.K2 : p.K1);
+            w_ok = k0 + kq * 4 < K;
+        }
+        if (!second) {
+#pragma unroll
+            for (int i = 0; i < Cfg::kLoadA; ++i)
+                stage_a[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_a1, off_a1[i], k0 * 4, 0));
+        } else {
+#pragma unroll
+            for (int i = 0; i < Cfg::kLoadA; ++i)
+                stage_a[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_a2, off_a2[i], (k0 - p.K1) * 4, 0));
+        }
+#pragma unroll
+        for (int i = 0; i < Cfg::kLoadB; ++i)
+            stage_b[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, off_w[i], k0 * 4, 0));
+    };
+    // fp32 registers -> P bf16 planes in LDS (8 bytes per plane and float4)
+    auto store_tile = [&](int buf) {
+        if (k_tail) {
+#pragma unroll
+            for (int i = 0; i < Cfg::kLoadA; ++i)
+                if (!a_ok) stage_a[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < Cfg::kLoadB; ++i)
+                if (!w_ok) stage_b[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        __bf16* a_lds = lds16 + buf * Cfg::kBufHalves;
+        __bf16* b_lds = a_lds + BM * P * LDT;
+#pragma unroll
+        for (int i = 0; i < Cfg::kLoadA; ++i) {
+            const int row = tid / kVecPerRow + i * kRowsPerPass;
+            unsigned int lo[P], hi[P];
+            split_pair<P>(stage_a[i][0], stage_a[i][1], lo);
+            split_pair<P>(stage_a[i][2], stage_a[i][3], hi);
+#pragma unroll
+            for (int pl = 0; pl < P; ++pl)
+                *reinterpret_cast<u32x2*>(a_lds + (pl * BM + row) * LDT + kq * 4) = u32x2{lo[pl], hi[pl]};
+        }
+#pragma unroll
+        for (int i = 0; i < Cfg::kLoadB; ++i) {
+            const int row = tid / kVecPerRow + i * kRowsPerPass;
+            unsigned int lo[P], hi[P];
+            split_pair<P>(stage_b[i][0], stage_b[i][1], lo);
+            split_pair<P>(stage_b[i][2], stage_b[i][3], hi);
+#pragma unroll
+            for (int pl = 0; pl < P; ++pl)
+                *reinterpret_cast<u32x2*>(b_lds + (pl * BN + row) * LDT + kq * 4) = u32x2{lo[pl], hi[pl]};
+        }
+    };
+
+    f32x16 acc[Cfg::TM][Cfg::TN];
+#pragma unroll
+    for (int i = 0; i < Cfg::TM; ++i)
+#pragma unroll
+        for (int j = 0; j < Cfg::TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+
+    const int frag_row = lane & 31;
+    const int frag_k = (lane >> 5) * 8;
+
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int buf = Cfg::kBufs == 2 ? (kt & 1) : 0;
+        if (kt + 1 < nkt) load_tile(kt + 1);
+
+        const __bf16* a_base = lds16 + buf * Cfg::kBufHalves + (wm * Cfg::kWaveM + frag_row) * LDT + frag_k;
+        const __bf16* b_base = lds16 + buf * Cfg::kBufHalves + BM * P * LDT + (wn * Cfg::kWaveN + frag_row) * LDT + frag_k;
+#pragma unroll
+        for (int ks = 0; ks < BK / 16; ++ks) {
+            bf16x8 a[P][Cfg::TM], b[P][Cfg::TN];
+#pragma unroll
+            for (int pl = 0; pl < P; ++pl) {
+#pragma unroll
+                for (int i = 0; i < Cfg::TM; ++i)
+                    a[pl][i] = *reinterpret_cast<const bf16x8*>(a_base + (pl * BM + i * 32) * LDT + ks * 16);
+#pragma unroll
+                for (int j = 0; j < Cfg::TN; ++j)
+                    b[pl][j] = *reinterpret_cast<const bf16x8*>(b_base + (pl * BN + j * 32) * LDT + ks * 16);
+            }
+            __builtin_amdgcn_s_setprio(1);
+            // plane products, smallest weight first: (pa, pb) with pa + pb = P - 1, ..., 0
+#pragma unroll
+            for (int w = P - 1; w >= 0; --w)
+#pragma unroll
+                for (int pa = 0; pa <= w; ++pa)
+#pragma unroll
+                    for (int i = 0; i < Cfg::TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < Cfg::TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[pa][i], b[w - pa][j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+        }
+
+        if (kt + 1 < nkt) {
+            if (Cfg::kBufs == 1) __syncthreads();      // every wave is done reading the only buffer
+            store_tile(Cfg::kBufs == 2 ? (buf ^ 1) : 0);
+        }
+        __syncthreads();
+    }
+
+    // Epilogue: as gemm_f32_mfma (D layout of a 32x32 tile: col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)).
+    const float* __restrict__ bias = p.seg[seg].bias;
+    float* __restrict__ C = p.seg[seg].C + (size_t)blockIdx.y * p.part_stride;
+    const int half = lane >> 5;
+    const bool has_res = p.R != nullptr;
+    const __amdgpu_buffer_rsrc_t rsrc_c = __builtin_amdgcn_make_buffer_rsrc(C, 0, p.M * p.ldc * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(has_res ? p.R : p.A1), 0,
+                                                                             has_res && p.res_mod == 0 ? p.M * p.ldr * 4 : 0, 0x00020000);
+    constexpr int kOutOfRange = 0x7ffffff0;
+#pragma unroll
+    for (int j = 0; j < Cfg::TN; ++j) {
+        const int n = n0 + wn * Cfg::kWaveN + j * 32 + (lane & 31);
+        const bool n_ok = n < p.seg_n;
+        const float bv = bias ? bias[min(n, p.seg_n - 1)] : 0.f;
+#pragma unroll
+        for (int i = 0; i < Cfg::TM; ++i) {
+            const int mbase = m0 + wm * Cfg::kWaveM + i * 32 + 4 * half;
+            float out[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float v = acc[i][j][r] + bv;
+                out[r] = p.act == 1 ? fmaxf(v, 0.f) : v;
+            }
+            if (has_res) {
+                float res[16];
+                if (p.res_mod == 0) {
+                    const int voff_r = n_ok ? (mbase * p.ldr + n) * 4 : kOutOfRange;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        res[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc_r, voff_r, ((r & 3) + 8 * (r >> 2)) * p.ldr * 4, 0));
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int mc = min(mbase + (r & 3) + 8 * (r >> 2), p.M - 1) % p.res_mod;
+                        res[r] = p.R[(size_t)mc * p.ldr + min(n, p.seg_n - 1)];
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) out[r] += res[r];
+            }
+            const int voff_c = n_ok ? (mbase * p.ldc + n) * 4 : kOutOfRange;
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, out[r]), rsrc_c, voff_c, ((r & 3) + 8 * (r >> 2)) * p.ldc * 4, 0);
+        }
+    }
+}

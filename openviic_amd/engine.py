@@ -73,10 +73,20 @@ class CaptionEngine:
     # pad the region axis to a multiple of this with zero rows before decoding (1 = exact shapes).  Results are
     # identical; with ragged real-data batches a bucket of 8 or 16 bounds the number of distinct shapes (graphs).
     region_bucket = int(os.environ.get("OVC_REGION_BUCKET", "1"))
+    # GEMM arithmetic: "f32" = fp32 MFMA, the parity mode (default, the only mode the headline numbers use).  Opt-in split
+    # precision: "bf16" / "bf16x3" / "bf16x6" cut every GEMM's fp32 operands into 1 / 2 / 3 bf16 planes and contract
+    # them on the 16-bit matrix path with fp32 accumulation (1 / 3 / 6 plane products) -- faster, fp32 in and out, but
+    # NOT bit-identical to "f32" (DESIGN.md has the measured token-id agreement of each mode).
+    PRECISIONS = {"f32": 0, "bf16": 1, "bf16x3": 2, "bf16x6": 3}
+    precision = os.environ.get("OVC_PRECISION", "f32")
 
-    def __init__(self, model, tune_concurrency=None):
+    def __init__(self, model, tune_concurrency=None, precision=None):
         self.lib = native.load()
         self.model = model
+        if precision is not None:
+            self.precision = precision
+        if self.precision not in self.PRECISIONS:
+            raise native.OvcError("precision must be one of {} (got {!r})".format(sorted(self.PRECISIONS), self.precision))
         if tune_concurrency is not None:          # per engine: e.g. 2 for a host that alternates batches over 3-4 streams
             self.tune_concurrency = int(tune_concurrency)
         self._keep = []          # tensors created here whose storage the pointer table references
@@ -136,6 +146,7 @@ class CaptionEngine:
         d.pos_emb = _p(dec.pos_emb.weight.detach())
         d.fc = _p(dec.fc.weight.detach())
         d.tune_objective = max(1, min(8, int(self.tune_concurrency)))
+        d.precision = self.PRECISIONS[self.precision]
         return d
 
     def _refresh_derived(self):

@@ -12,7 +12,7 @@ OVC_MAX_LAYERS = 8
 OVC_MAX_LEVELS = 4
 OVC_MAX_BEAM = 8
 OVC_PROFILE_CLASSES = 4
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 _ERRORS = {-1: "OVC_EINVAL (bad argument / unsupported shape)", -2: "OVC_EWORKSPACE (workspace too small)",
            -3: "OVC_ELAUNCH (HIP launch failed)"}
@@ -56,7 +56,7 @@ class Model(ctypes.Structure):
         ("bos_idx", c_int32), ("eos_idx", c_int32), ("ln_eps", c_float),
         ("proj", Lin), ("enc_ln", Norm), ("fc_g_w", c_void_p), ("fc_g_b", c_void_p),
         ("enc", EncLayer * OVC_MAX_LAYERS), ("dec", DecLayer * OVC_MAX_LAYERS),
-        ("word_emb", c_void_p), ("pos_emb", c_void_p), ("fc", c_void_p), ("tune_objective", c_int32),
+        ("word_emb", c_void_p), ("pos_emb", c_void_p), ("fc", c_void_p), ("tune_objective", c_int32), ("precision", c_int32),
     ]
 
 

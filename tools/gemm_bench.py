@@ -3,7 +3,8 @@
 
 For every (shape, K-order class, K split) the engine issues: time of each tiling of that class
 (ovc_debug_linear_tiling, back-to-back launches issued from C) and of torch.addmm (rocBLAS / hipBLASLt) as a
-same-hardware reference.  Random operands.   python tools/gemm_bench.py [decode|encoder|all]
+same-hardware reference.  Random operands.   python tools/gemm_bench.py [decode|encoder|all] [split]
+With "split": also the opt-in split-precision classes (bf16 planes, gemm_split.h) with their error against an fp64 product.
 """
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -26,7 +27,10 @@ def tilings(lib):
     while lib.ovc_profile_kernel_name(t):
         name = lib.ovc_profile_kernel_name(t).decode()
         v = [int(x) for x in name[name.index("<") + 1:-1].split(",")]
-        out.append((t, "%dx%d w%d b%d c%d" % (v[0], v[1], v[4], v[5], v[6]), v[4] * v[6]))
+        if "bf16_split" in name:
+            out.append((t, "%dx%d p%d" % (v[0], v[1], v[5]), 100 + v[5]))
+        else:
+            out.append((t, "%dx%d w%d b%d c%d" % (v[0], v[1], v[4], v[5], v[6]), v[4] * v[6]))
         t += 1
     return out
 
@@ -48,6 +52,7 @@ def time_tiling(lib, x, w, b, y, t, ksplit, iters=40):
 
 def main():
     which = sys.argv[1] if len(sys.argv) > 1 else "all"
+    split = "split" in sys.argv[2:]
     lib = native.load()
     shapes = (DECODE if which in ("decode", "all") else []) + (ENCODER if which in ("encoder", "all") else [])
     tl = tilings(lib)
@@ -77,6 +82,25 @@ def main():
         print("%-16s %5dx%5dx%4d c%d /%d | torch %6.1f us | ideal %5.1f | %s" % (
             note, M, N, K, chains, ksplit, ref, flops / 157.3e6,
             "  ".join("%s: %.1f (%.0f TF)" % (l, u, flops / u / 1e6) for u, l in cells if u < 1e8)), flush=True)
+        if not split:
+            continue
+        exact = (x.double() @ w.double().t())
+        scale = exact.abs().mean().item()
+        for cls in (chains, 101, 102, 103):
+            cells, err = [], None
+            for t, label, c in tl:
+                if c != cls:
+                    continue
+                us = time_tiling(lib, x, w, b, y, t, ksplit)
+                if us is None:
+                    continue
+                cells.append((us, label))
+                if err is None:
+                    got = y[:max(ksplit, 1)].double().sum(0) + (b.double() if ksplit <= 1 else 0)
+                    err = ((got - exact - (b.double() if ksplit <= 1 else 0)).abs().max().item() / scale)
+            cells.sort()
+            print("    class %3d: max |err| / mean |y| = %.2e | %s" % (
+                cls, err, "  ".join("%s: %.1f (%.0f TF-eq)" % (l, u, flops / u / 1e6) for u, l in cells)), flush=True)
 
 
 if __name__ == "__main__":
