@@ -173,10 +173,12 @@ typedef struct {
     int32_t precision;                /* 0 = fp32 MFMA everywhere: the parity mode and the only one the headline numbers
                                          use.  1 / 2 / 3 = OPT-IN split precision: every GEMM of the engine cuts its fp32
                                          operands into that many bf16 planes and contracts them on the 16-bit matrix path
-                                         with fp32 accumulation (1, 3 or 6 plane products: "bf16", "bf16x3", "bf16x6";
-                                         K-order classes 101..103).  fp32 in, fp32 out, attention / LayerNorm / selection
-                                         unchanged; results differ from mode 0 in the low-order bits (3), at ~1e-5 (2)
-                                         or ~1e-2 (1) relative -- see DESIGN.md for measured token-id agreement.       */
+                                         with fp32 accumulation (1, 3 or 6 plane products: "bf16", "bf16x3", "bf16x6");
+                                         4 = two fp16 planes with a scaled residual, 3 products ("f16x3"; operands must
+                                         lie in fp16's range).  K-order classes 101..104.  fp32 in, fp32 out, attention /
+                                         LayerNorm / selection unchanged; results differ from mode 0 in the low-order
+                                         bits (3, 4), at ~1e-5 (2) or ~1e-2 (1) relative -- see DESIGN.md for the
+                                         measured token-id agreement.                                                  */
 } ovc_model;
 
 /* Sizes the engine accepts (anything else: ovc_workspace_bytes returns 0, the calls OVC_EINVAL) -- the
@@ -239,8 +241,8 @@ const char* ovc_profile_kernel_name(int tiling);   /* "" past the last tiling */
  *   kchains = 4   four interleaved chains summed in chain order (the engine's M = B*beam decode-step products);
  *   ksplit  = s   K cut into s contiguous slices whose raw partial products the consuming LayerNorm sums in
  *                 slice order (engine only; a fixed function of K).
- *   kchains = 101 / 102 / 103   the opt-in split-precision classes (ovc_model::precision = 1 / 2 / 3): one chain of
- *                 16-deep bf16 MFMA steps, plane products in a fixed order.
+ *   kchains = 101 .. 104   the opt-in split-precision classes (ovc_model::precision = 1 .. 4): one chain of
+ *                 16-deep 16-bit MFMA steps, plane products in a fixed order.
  * All tilings of one class produce bit-identical results, so token ids do not depend on the batch size, on the
  * GPU box or on what a timing run picked (the reference is deterministic on CPU: torch.sort path,
  * models/modules/beam_search.py:36-39).

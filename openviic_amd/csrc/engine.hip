@@ -41,7 +41,7 @@ namespace {
 // ---------------------------------------------------------------------------------------------
 struct ProfileRecord { hipEvent_t start, stop; double flops; int cls, tiling; };
 struct ProfileBin { int64_t launches; double ms, flops; };
-constexpr int kProfileTilings = 40;
+constexpr int kProfileTilings = 48;
 std::atomic<bool> g_profile_on{false};
 std::mutex g_profile_mutex;                      // guards everything below (several host threads may decode at once)
 std::vector<ProfileRecord> g_profile;            // open records (events not yet resolved)
@@ -123,7 +123,7 @@ bool model_ok(const ovc_model* m) {
     if ((m->d_feat & 3) || (m->d_ff & 3) || m->heads <= 0 || m->heads > 32 || m->heads * m->d_k > 1024 || m->vocab <= 1) return false;
     if (m->d_feat <= 0 || m->d_ff <= 0 || m->memory < 0) return false;
     if (m->max_len < 1 || m->max_len > 64) return false;
-    if (m->precision < 0 || m->precision > 3 || m->tune_objective < 0 || m->tune_objective > 8) return false;
+    if (m->precision < 0 || m->precision > 4 || m->tune_objective < 0 || m->tune_objective > 8) return false;
     if (m->bos_idx < 0 || m->bos_idx >= m->vocab || m->pad_idx < 0 || m->pad_idx >= m->vocab || m->eos_idx < 0 || m->eos_idx >= m->vocab) return false;
     // fused q|k|v and cross k|v GEMMs need segment widths that are multiples of the 64-wide tile
     if ((m->heads * m->d_k) % 64 || (m->heads * m->d_v) % 64 || (m->heads * m->d_k) != (m->heads * m->d_v)) return false;

@@ -84,7 +84,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return base + (bid >> 3);
 }
 
-#include "gemm_split.h"   // gemm_bf16_split: the opt-in split-precision classes (bf16 planes on the 16-bit matrix path)
+#include "gemm_split.h"   // gemm_split_mfma: the opt-in split-precision classes (bf16 planes on the 16-bit matrix path)
 
 // Registers are capped where residency matters: the M = 1280 decode products come as 1280 workgroups of 32x64 tiles,
 // five per CU -- with more than 96 registers only four are resident and the fifth runs as a second round (35 vs 28 us).
@@ -413,32 +413,33 @@ int launch_config(const GemmArgs& a, hipStream_t stream, const GemmLaunchOpts& o
     return OVC_OK;
 }
 
-template <int BM, int BN, int WM, int WN, int BK, int P>
+template <int BM, int BN, int WM, int WN, int BK, int MODE>
 int launch_split_config(const GemmArgs& a, hipStream_t stream, const GemmLaunchOpts& opts) {
-    using Cfg = SplitConfig<BM, BN, WM, WN, BK, P>;
+    using Cfg = SplitConfig<BM, BN, WM, WN, BK, MODE>;
     const int tiles_m = (a.M + BM - 1) / BM;
     const int tiles_n = (a.seg_n + BN - 1) / BN;
     const int grid = tiles_m * tiles_n * a.nseg;
     const size_t lds_bytes = Cfg::kLdsBytes;
     static std::once_flag attr_once;
     std::call_once(attr_once, [&] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_split<BM, BN, WM, WN, BK, P>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_split_mfma<BM, BN, WM, WN, BK, MODE>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     });
     int group_m, xcd_pm;
     tile_order(a, tiles_m, tiles_n, &group_m, &xcd_pm);
     const dim3 grid3(grid, a.ksplit > 1 ? a.ksplit : 1, opts.copies > 1 ? opts.copies : 1);
     if (opts.start && opts.stop)
-        hipExtLaunchKernelGGL((gemm_bf16_split<BM, BN, WM, WN, BK, P>), grid3, dim3(256), (uint32_t)lds_bytes, stream,
+        hipExtLaunchKernelGGL((gemm_split_mfma<BM, BN, WM, WN, BK, MODE>), grid3, dim3(256), (uint32_t)lds_bytes, stream,
                               opts.start, opts.stop, 0, a, tiles_m, tiles_n, group_m, xcd_pm);
     else
-        hipLaunchKernelGGL((gemm_bf16_split<BM, BN, WM, WN, BK, P>), grid3, dim3(256), lds_bytes, stream, a, tiles_m, tiles_n, group_m, xcd_pm);
+        hipLaunchKernelGGL((gemm_split_mfma<BM, BN, WM, WN, BK, MODE>), grid3, dim3(256), lds_bytes, stream, a, tiles_m, tiles_n, group_m, xcd_pm);
     OVC_RETURN_IF_LAUNCH_FAILED();
     return OVC_OK;
 }
 
 // bm, bn, wm, wn, wk, bk, nc, planes.  fp32 tilings (planes = 0): chains = wk * nc is the K-order class the instance
-// belongs to; split-precision tilings (planes = 1..3): class 100 + planes (kSplitClass).
+// belongs to; split-precision tilings (planes = the kernel's MODE: 1..3 bf16 planes, 4 = two fp16 planes): class
+// 100 + MODE (kSplitClass).
 struct TilingInfo { int bm, bn, wm, wn, wk, bk, nc, planes; };
 constexpr int kSplitClass = 100;
 #define OVC_TILINGS(X)                                                                                   \
@@ -457,16 +458,20 @@ constexpr int kSplitClass = 100;
 #define OVC_SPLIT_SHAPES(X, first, planes)                                                                \
     X(first + 0, 128, 128, 2, 2, 32, planes) X(first + 1, 64, 128, 2, 2, 32, planes) X(first + 2, 128, 64, 2, 2, 32, planes) \
     X(first + 3, 64, 64, 2, 2, 32, planes) X(first + 4, 32, 128, 1, 4, 32, planes)
-#define OVC_SPLIT_TILINGS(X) OVC_SPLIT_SHAPES(X, 17, 1) OVC_SPLIT_SHAPES(X, 22, 2) OVC_SPLIT_SHAPES(X, 27, 3)
+// deep K tiles for the M = B*k decode products: their MFMA block per K tile is a fraction of a microsecond, so a K loop is
+// a chain of load latencies and fewer, larger tiles halve it
+#define OVC_SPLIT_DEEP(X, first, planes) X(first + 0, 64, 64, 2, 2, 64, planes) X(first + 1, 64, 128, 2, 2, 64, planes)
+#define OVC_SPLIT_TILINGS(X) OVC_SPLIT_SHAPES(X, 17, 1) OVC_SPLIT_SHAPES(X, 22, 2) OVC_SPLIT_SHAPES(X, 27, 3) OVC_SPLIT_SHAPES(X, 32, 4) \
+    OVC_SPLIT_DEEP(X, 37, 1) OVC_SPLIT_DEEP(X, 39, 2) OVC_SPLIT_DEEP(X, 41, 3) OVC_SPLIT_DEEP(X, 43, 4)
 #define OVC_TILING_INFO(id, bm, bn, wm, wn, wk, bk, nc) {bm, bn, wm, wn, wk, bk, nc, 0},
 #define OVC_SPLIT_INFO(id, bm, bn, wm, wn, bk, planes) {bm, bn, wm, wn, 1, bk, 1, planes},
 constexpr TilingInfo kTilings[] = {OVC_TILINGS(OVC_TILING_INFO) OVC_SPLIT_TILINGS(OVC_SPLIT_INFO)};
 #undef OVC_TILING_INFO
 #undef OVC_SPLIT_INFO
 constexpr int kNumTilings = sizeof(kTilings) / sizeof(kTilings[0]);
-static_assert(kNumTilings == 32, "tiling ids: 17 fp32 + 15 split-precision");
+static_assert(kNumTilings == 45, "tiling ids: 17 fp32 + 28 split-precision");
 inline int tiling_chains(int t) { return kTilings[t].planes ? kSplitClass + kTilings[t].planes : kTilings[t].wk * kTilings[t].nc; }
-inline bool class_ok(int c) { return c == 1 || c == 4 || (c > kSplitClass && c <= kSplitClass + 3); }
+inline bool class_ok(int c) { return c == 1 || c == 4 || (c > kSplitClass && c <= kSplitClass + 4); }
 
 // Debug hook (ovc_debug_force_gemm_tiling): applies to every launch that does not carry its own
 // GemmLaunchOpts::forced_tiling and whose class matches; not for use while other threads decode.
@@ -509,9 +514,10 @@ double tiling_cost(const GemmArgs& a, const TilingInfo& t) {
     const long wgs = (long)((a.M + t.bm - 1) / t.bm) * ((a.seg_n + t.bn - 1) / t.bn) * a.nseg;
     const double per_cu = (double)((wgs + 255) / 256);                       // workgroups on the busiest CU
     // split precision: planes (planes + 1) / 2 bf16 MFMAs of 32 cycles per 16-deep step against one fp32 MFMA of 64 per 2
-    const double k_units = t.planes ? K / 16.0 * (t.planes * (t.planes + 1) / 2) * 0.5 : K / 2.0;
+    const int products = t.planes == 4 ? 3 : t.planes * (t.planes + 1) / 2;      // mode 4: two fp16 planes
+    const double k_units = t.planes ? K / 16.0 * products * 0.5 : K / 2.0;
     const double mfma_per_wave = (double)(t.bm / 32) * (t.bn / 32) * k_units / 4.0;
-    const double overhead = 48.0 + (t.bk >= 64 ? 1e9 : 0.0);                 // BK=64 tilings: only when measured or forced
+    const double overhead = 48.0 + (t.bk >= 64 && !t.planes ? 1e9 : 0.0);    // fp32 BK=64 tilings: only when measured or forced
     const double bytes_per_flop = 2.0 * (t.bm + t.bn) / (double)(t.bm * t.bn);   // operand floats per MAC
     const double bw_penalty = 1.0 + 4.0 * bytes_per_flop;                    // 128x128: 1.06, 32x32: 1.5
     return per_cu * (mfma_per_wave * bw_penalty + overhead);
@@ -539,7 +545,7 @@ extern "C" int ovc_debug_force_gemm_tiling(int tiling) {
 
 const char* ovc_gemm_tiling_name(int tiling) {
 #define OVC_TILING_NAME(id, bm, bn, wm, wn, wk, bk, nc) "gemm_f32_mfma<" #bm ", " #bn ", " #wm ", " #wn ", " #wk ", " #bk ", " #nc ">",
-#define OVC_SPLIT_NAME(id, bm, bn, wm, wn, bk, planes) "gemm_bf16_split<" #bm ", " #bn ", " #wm ", " #wn ", " #bk ", " #planes ">",
+#define OVC_SPLIT_NAME(id, bm, bn, wm, wn, bk, planes) "gemm_split_mfma<" #bm ", " #bn ", " #wm ", " #wn ", " #bk ", " #planes ">",
     static const char* names[] = {OVC_TILINGS(OVC_TILING_NAME) OVC_SPLIT_TILINGS(OVC_SPLIT_NAME)};
 #undef OVC_TILING_NAME
 #undef OVC_SPLIT_NAME

@@ -1,6 +1,7 @@
 // Split-precision GEMM (included by gemm.hip inside its anonymous namespace): the same product
 //     C[M,N] = act([A1|A2] . W^T + bias) + R      on fp32 operands in HBM, fp32 result,
-// with the contraction on the 16-bit matrix path (v_mfma_f32_32x32x16_bf16, 16x the fp32 MFMA rate) and fp32 accumulation.
+// with the contraction on the 16-bit matrix path (v_mfma_f32_32x32x16_bf16 / _f16, 16x the fp32 MFMA rate) and fp32
+// accumulation.
 // NOT the parity mode: an opt-in (ovc_model::precision), measured and reported separately from the fp32 headline.
 //
 // Each fp32 operand element x is cut into P bf16 "planes" while its tile is staged into LDS:
@@ -9,6 +10,11 @@
 //     P = 1   a0 b0                                   bf16 inputs:  8 mantissa bits per operand (error ~ 2^-9 per product)
 //     P = 2   a0 b0 + a0 b1 + a1 b0                   3 products:  16 bits per operand (~ 2^-17)
 //     P = 3   ... + a0 b2 + a1 b1 + a2 b0             6 products:  24 bits, the dropped terms are below fp32's own rounding
+//   MODE 4 ("f16x3"): two fp16 planes with the residual scaled into fp16's normal range,
+//     p0 = f16(x), p1 = f16((x - p0) * 2^11);   a0 b0 in one accumulator, a0 b1 + a1 b0 in a second one that joins
+//     the first with the factor 2^-11 in the epilogue: 22 bits per operand from 3 products (fp16 carries 11 bits where
+//     bf16 carries 8) -- close to the 6-product bf16 mode's accuracy at the 3-product mode's cost.  Operands must lie
+//     inside fp16's range (|x| < 65504); smaller than 6e-5 they keep an absolute accuracy of 3e-11.
 // The small terms are accumulated first.  One summation chain over k per output (16-deep MFMA steps in order, products
 // in the fixed order above), whatever the tiling: all tilings of one P give the same bits, so the tuner may pick freely,
 // exactly as inside the fp32 K-order classes (gemm.hip).
@@ -23,11 +29,21 @@
 
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
-template <int BM, int BN, int WM, int WN, int BK, int P>
+constexpr bool split_is_half(int mode) { return mode == 4; }
+constexpr int split_planes(int mode) { return mode == 4 ? 2 : mode; }
+constexpr float kHalfResidualScale = 2048.f;      // 2^11: the residual of an 11-bit plane, back in fp16's normal range
+
+template <int BM, int BN, int WM, int WN, int BK, int MODE>
 struct SplitConfig {
+    static constexpr int P = split_planes(MODE);
+    static constexpr bool kHalf = split_is_half(MODE);
+    static constexpr int kAcc = kHalf ? P : 1;                  // accumulators: one per weight level when levels carry a scale
     static constexpr int LDT = BK + 8;                          // padded LDS row stride (halves)
     static constexpr int kWaveM = BM / WM, kWaveN = BN / WN;
     static constexpr int TM = kWaveM / 32, TN = kWaveN / 32;
@@ -41,30 +57,48 @@ struct SplitConfig {
     static_assert(BK % 16 == 0, "a K tile holds whole 16-deep MFMA steps");
     static_assert(kWaveM % 32 == 0 && kWaveN % 32 == 0, "wave tile must be a multiple of 32x32");
     static_assert(kLoadA >= 1 && kLoadB >= 1, "tile too small for 256 loader threads");
-    static_assert(P >= 1 && P <= 3, "one, two or three bf16 planes");
+    static_assert(MODE >= 1 && MODE <= 4, "1..3 bf16 planes, or (4) two fp16 planes");
 };
 
-// Two neighbouring elements -> P packed bf16 pairs (element 0 in the low half).
-template <int P>
-__device__ __forceinline__ void split_pair(float a, float b, unsigned int (&out)[P]) {
+// Two neighbouring elements -> P packed 16-bit pairs (element 0 in the low half).
+template <int MODE>
+__device__ __forceinline__ void split_pair(float a, float b, unsigned int (&out)[split_planes(MODE)]) {
+    constexpr int P = split_planes(MODE);
 #pragma unroll
     for (int p = 0; p < P; ++p) {
-        const unsigned int pk = __builtin_bit_cast(unsigned int, __builtin_convertvector((f32x2{a, b}), bf16x2));
-        out[p] = pk;
-        if (p + 1 < P) {
-            a -= __builtin_bit_cast(float, pk << 16);
-            b -= __builtin_bit_cast(float, pk & 0xffff0000u);
+        if (split_is_half(MODE)) {
+            const f16x2 h = __builtin_convertvector((f32x2{a, b}), f16x2);
+            out[p] = __builtin_bit_cast(unsigned int, h);
+            if (p + 1 < P) {
+                a = (a - (float)h[0]) * kHalfResidualScale;
+                b = (b - (float)h[1]) * kHalfResidualScale;
+            }
+        } else {
+            const unsigned int pk = __builtin_bit_cast(unsigned int, __builtin_convertvector((f32x2{a, b}), bf16x2));
+            out[p] = pk;
+            if (p + 1 < P) {
+                a -= __builtin_bit_cast(float, pk << 16);
+                b -= __builtin_bit_cast(float, pk & 0xffff0000u);
+            }
         }
     }
 }
 
-template <int BM, int BN, int WM, int WN, int BK, int P>
-__global__ __launch_bounds__(256) void gemm_bf16_split(GemmArgs p, int tiles_m, int tiles_n_per_seg, int group_m, int xcd_pm) {
-    using Cfg = SplitConfig<BM, BN, WM, WN, BK, P>;
+template <int MODE>
+__device__ __forceinline__ f32x16 split_mma(const u32x4& a, const u32x4& b, const f32x16& c) {
+    if (split_is_half(MODE))
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+template <int BM, int BN, int WM, int WN, int BK, int MODE>
+__global__ __launch_bounds__(256) void gemm_split_mfma(GemmArgs p, int tiles_m, int tiles_n_per_seg, int group_m, int xcd_pm) {
+    using Cfg = SplitConfig<BM, BN, WM, WN, BK, MODE>;
+    constexpr int P = Cfg::P;
     constexpr int LDT = Cfg::LDT;
     constexpr int kVecPerRow = BK / 4;
     constexpr int kRowsPerPass = 256 / kVecPerRow;
-    extern __shared__ __attribute__((aligned(16))) __bf16 lds16[];
+    extern __shared__ __attribute__((aligned(16))) unsigned short lds16[];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -152,14 +186,14 @@ __global__ __launch_bounds__(256) void gemm_bf16_split(GemmArgs p, int tiles_m, 
             for (int i = 0; i < Cfg::kLoadB; ++i)
                 if (!w_ok) stage_b[i] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
-        __bf16* a_lds = lds16 + buf * Cfg::kBufHalves;
-        __bf16* b_lds = a_lds + BM * P * LDT;
+        unsigned short* a_lds = lds16 + buf * Cfg::kBufHalves;
+        unsigned short* b_lds = a_lds + BM * P * LDT;
 #pragma unroll
         for (int i = 0; i < Cfg::kLoadA; ++i) {
             const int row = tid / kVecPerRow + i * kRowsPerPass;
             unsigned int lo[P], hi[P];
-            split_pair<P>(stage_a[i][0], stage_a[i][1], lo);
-            split_pair<P>(stage_a[i][2], stage_a[i][3], hi);
+            split_pair<MODE>(stage_a[i][0], stage_a[i][1], lo);
+            split_pair<MODE>(stage_a[i][2], stage_a[i][3], hi);
 #pragma unroll
             for (int pl = 0; pl < P; ++pl)
                 *reinterpret_cast<u32x2*>(a_lds + (pl * BM + row) * LDT + kq * 4) = u32x2{lo[pl], hi[pl]};
@@ -168,21 +202,23 @@ __global__ __launch_bounds__(256) void gemm_bf16_split(GemmArgs p, int tiles_m, 
         for (int i = 0; i < Cfg::kLoadB; ++i) {
             const int row = tid / kVecPerRow + i * kRowsPerPass;
             unsigned int lo[P], hi[P];
-            split_pair<P>(stage_b[i][0], stage_b[i][1], lo);
-            split_pair<P>(stage_b[i][2], stage_b[i][3], hi);
+            split_pair<MODE>(stage_b[i][0], stage_b[i][1], lo);
+            split_pair<MODE>(stage_b[i][2], stage_b[i][3], hi);
 #pragma unroll
             for (int pl = 0; pl < P; ++pl)
                 *reinterpret_cast<u32x2*>(b_lds + (pl * BN + row) * LDT + kq * 4) = u32x2{lo[pl], hi[pl]};
         }
     };
 
-    f32x16 acc[Cfg::TM][Cfg::TN];
+    f32x16 acc[Cfg::kAcc][Cfg::TM][Cfg::TN];
 #pragma unroll
-    for (int i = 0; i < Cfg::TM; ++i)
+    for (int c = 0; c < Cfg::kAcc; ++c)
 #pragma unroll
-        for (int j = 0; j < Cfg::TN; ++j)
+        for (int i = 0; i < Cfg::TM; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            for (int j = 0; j < Cfg::TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[c][i][j][r] = 0.f;
 
     load_tile(0);
     store_tile(0);
@@ -195,19 +231,19 @@ __global__ __launch_bounds__(256) void gemm_bf16_split(GemmArgs p, int tiles_m, 
         const int buf = Cfg::kBufs == 2 ? (kt & 1) : 0;
         if (kt + 1 < nkt) load_tile(kt + 1);
 
-        const __bf16* a_base = lds16 + buf * Cfg::kBufHalves + (wm * Cfg::kWaveM + frag_row) * LDT + frag_k;
-        const __bf16* b_base = lds16 + buf * Cfg::kBufHalves + BM * P * LDT + (wn * Cfg::kWaveN + frag_row) * LDT + frag_k;
+        const unsigned short* a_base = lds16 + buf * Cfg::kBufHalves + (wm * Cfg::kWaveM + frag_row) * LDT + frag_k;
+        const unsigned short* b_base = lds16 + buf * Cfg::kBufHalves + BM * P * LDT + (wn * Cfg::kWaveN + frag_row) * LDT + frag_k;
 #pragma unroll
         for (int ks = 0; ks < BK / 16; ++ks) {
-            bf16x8 a[P][Cfg::TM], b[P][Cfg::TN];
+            u32x4 a[P][Cfg::TM], b[P][Cfg::TN];
 #pragma unroll
             for (int pl = 0; pl < P; ++pl) {
 #pragma unroll
                 for (int i = 0; i < Cfg::TM; ++i)
-                    a[pl][i] = *reinterpret_cast<const bf16x8*>(a_base + (pl * BM + i * 32) * LDT + ks * 16);
+                    a[pl][i] = *reinterpret_cast<const u32x4*>(a_base + (pl * BM + i * 32) * LDT + ks * 16);
 #pragma unroll
                 for (int j = 0; j < Cfg::TN; ++j)
-                    b[pl][j] = *reinterpret_cast<const bf16x8*>(b_base + (pl * BN + j * 32) * LDT + ks * 16);
+                    b[pl][j] = *reinterpret_cast<const u32x4*>(b_base + (pl * BN + j * 32) * LDT + ks * 16);
             }
             __builtin_amdgcn_s_setprio(1);
             // plane products, smallest weight first: (pa, pb) with pa + pb = P - 1, ..., 0
@@ -219,7 +255,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_split(GemmArgs p, int tiles_m, 
                     for (int i = 0; i < Cfg::TM; ++i)
 #pragma unroll
                         for (int j = 0; j < Cfg::TN; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[pa][i], b[w - pa][j], acc[i][j], 0, 0, 0);
+                            acc[Cfg::kHalf ? w : 0][i][j] = split_mma<MODE>(a[pa][i], b[w - pa][j], acc[Cfg::kHalf ? w : 0][i][j]);
             __builtin_amdgcn_s_setprio(0);
         }
 
@@ -228,6 +264,19 @@ __global__ __launch_bounds__(256) void gemm_bf16_split(GemmArgs p, int tiles_m, 
             store_tile(Cfg::kBufs == 2 ? (buf ^ 1) : 0);
         }
         __syncthreads();
+    }
+
+    // fp16 planes: weight level w was accumulated at scale 2^(11 w); smallest level first
+    if (Cfg::kHalf) {
+#pragma unroll
+        for (int c = Cfg::kAcc - 1; c > 0; --c)
+#pragma unroll
+            for (int i = 0; i < Cfg::TM; ++i)
+#pragma unroll
+                for (int j = 0; j < Cfg::TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        acc[c - 1][i][j][r] = fmaf(acc[c][i][j][r], 1.f / kHalfResidualScale, acc[c - 1][i][j][r]);
     }
 
     // Epilogue: as gemm_f32_mfma (D layout of a 32x32 tile: col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)).
@@ -250,7 +299,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_split(GemmArgs p, int tiles_m, 
             float out[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float v = acc[i][j][r] + bv;
+                const float v = acc[0][i][j][r] + bv;
                 out[r] = p.act == 1 ? fmaxf(v, 0.f) : v;
             }
             if (has_res) {

@@ -75,9 +75,10 @@ class CaptionEngine:
     region_bucket = int(os.environ.get("OVC_REGION_BUCKET", "1"))
     # GEMM arithmetic: "f32" = fp32 MFMA, the parity mode (default, the only mode the headline numbers use).  Opt-in split
     # precision: "bf16" / "bf16x3" / "bf16x6" cut every GEMM's fp32 operands into 1 / 2 / 3 bf16 planes and contract
-    # them on the 16-bit matrix path with fp32 accumulation (1 / 3 / 6 plane products) -- faster, fp32 in and out, but
-    # NOT bit-identical to "f32" (DESIGN.md has the measured token-id agreement of each mode).
-    PRECISIONS = {"f32": 0, "bf16": 1, "bf16x3": 2, "bf16x6": 3}
+    # them on the 16-bit matrix path with fp32 accumulation (1 / 3 / 6 plane products); "f16x3" uses two fp16 planes
+    # (scaled residual, 3 products, 22 bits per operand) -- faster, fp32 in and out, but NOT bit-identical to "f32"
+    # (DESIGN.md has the measured token-id agreement of each mode).
+    PRECISIONS = {"f32": 0, "bf16": 1, "bf16x3": 2, "bf16x6": 3, "f16x3": 4}
     precision = os.environ.get("OVC_PRECISION", "f32")
 
     def __init__(self, model, tune_concurrency=None, precision=None):
@@ -147,6 +148,12 @@ class CaptionEngine:
         d.fc = _p(dec.fc.weight.detach())
         d.tune_objective = max(1, min(8, int(self.tune_concurrency)))
         d.precision = self.PRECISIONS[self.precision]
+        if self.precision == "f16x3":
+            # fp16 planes: an operand beyond fp16's range would turn into inf; the weights can be checked here, once
+            top = max(float(p.detach().abs().max()) for p in model.parameters() if p.numel())
+            if not top < 65504.0:
+                raise native.OvcError("precision='f16x3' needs every weight inside fp16's range (largest |w| = {:g}); "
+                                      "use 'bf16x6' or the default 'f32'".format(top))
         return d
 
     def _refresh_derived(self):

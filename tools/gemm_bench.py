@@ -27,8 +27,8 @@ def tilings(lib):
     while lib.ovc_profile_kernel_name(t):
         name = lib.ovc_profile_kernel_name(t).decode()
         v = [int(x) for x in name[name.index("<") + 1:-1].split(",")]
-        if "bf16_split" in name:
-            out.append((t, "%dx%d p%d" % (v[0], v[1], v[5]), 100 + v[5]))
+        if "split_mfma" in name:
+            out.append((t, "%dx%d b%d p%d" % (v[0], v[1], v[4], v[5]), 100 + v[5]))
         else:
             out.append((t, "%dx%d w%d b%d c%d" % (v[0], v[1], v[4], v[5], v[6]), v[4] * v[6]))
         t += 1
@@ -86,7 +86,7 @@ def main():
             continue
         exact = (x.double() @ w.double().t())
         scale = exact.abs().mean().item()
-        for cls in (chains, 101, 102, 103):
+        for cls in (chains, 101, 102, 103, 104):
             cells, err = [], None
             for t, label, c in tl:
                 if c != cls:
@@ -95,9 +95,9 @@ def main():
                 if us is None:
                     continue
                 cells.append((us, label))
-                if err is None:
-                    got = y[:max(ksplit, 1)].double().sum(0) + (b.double() if ksplit <= 1 else 0)
-                    err = ((got - exact - (b.double() if ksplit <= 1 else 0)).abs().max().item() / scale)
+                if err is None:      # (ksplit > 1: raw partial products, no bias)
+                    want = exact + b.double() if ksplit <= 1 else exact
+                    err = (y[:max(ksplit, 1)].double().sum(0) - want).abs().max().item() / scale
             cells.sort()
             print("    class %3d: max |err| / mean |y| = %.2e | %s" % (
                 cls, err, "  ".join("%s: %.1f (%.0f TF-eq)" % (l, u, flops / u / 1e6) for u, l in cells)), flush=True)
