@@ -12,7 +12,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SOURCES = ["gemm.hip", "rowops.hip", "attention.hip", "beam.hip", "engine.hip"]
-HEADERS = ["common.h", os.path.join("..", "..", "include", "ovc.h")]
+HEADERS = ["common.h", "gemm_split.h", os.path.join("..", "..", "include", "ovc.h")]
 LIBRARY = os.path.join(HERE, "libovc.so")
 ARCH = "gfx950"
 

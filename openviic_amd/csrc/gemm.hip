@@ -14,9 +14,8 @@
 //   * Row stride 36 floats: 36*r mod 64 hits 16 distinct 4-bank slots for any 16 rows that are
 //     distinct mod 16, which is exactly what each ds_read_b128 lane group contains -> no bank
 //     conflicts.
-//   * 256 threads = 4 waves = one wave per SIMD; LDS double-buffered with one barrier per
-//     32-deep K tile; the next tile's global loads are issued before the MFMA block and written
-//     to LDS after it (issue-early / write-late).
+//   * 256 threads = 4 waves = one wave per SIMD; one LDS tile (OVC_F32_BUFS); the next tile's global loads are
+//     issued before the MFMA block and written to LDS after it, behind a barrier (issue-early / write-late).
 //   * blockIdx is remapped so that each of the 8 XCDs (private L2s) works on a contiguous part of the tile
 //     grid: super-rows of 8 M tiles swept over N when the A panel exceeds L2, otherwise a 2-D split
 //     pm x 8/pm chosen on the host to minimise the operand bytes the XCDs pull from the Infinity Cache.
@@ -57,6 +56,14 @@ namespace {
 // of 1280 x 512 is only 640 MFMA tiles for 1024 SIMDs; giving the four chains of a 32x32 tile to four waves
 // turns that into 2560 wave-sized tasks without any cross-workgroup reduction.
 // NC * WK = number of chains of the K-order class: 1 (WK = 1, NC = 1) or 4.
+// LDS tile buffers.  1 (default): one buffer -- the next K tile waits in registers and is written after a second barrier.
+// Half the LDS per workgroup lets twice as many workgroups share a CU, which is worth more than the barrier: same box,
+// alternating runs (tools/gemm_bench.py), best tiling per shape, 2 buffers -> 1: feature projection 247 -> 225 us, encoder
+// o-proj 66.0 -> 60.4, encoder FFN-1 227 -> 211, vocabulary 123 -> 117, decode o-proj 12.0 -> 11.2, q|k|v 23.6 -> 22.7, FFN 28.7 ->
+// 27.7; single-stream batch 15.26 -> 14.95 ms, four streams +-1 %.  2: double-buffered, one barrier per K tile (round 1).
+#ifndef OVC_F32_BUFS
+#define OVC_F32_BUFS 1
+#endif
 template <int BM, int BN, int WM, int WN, int WK, int BK, int NC>
 struct TileConfig {
     static constexpr int LDT = BK + 4;             // padded LDS row stride (floats)
@@ -68,13 +75,16 @@ struct TileConfig {
     static constexpr int kLoadA = BM * (BK / 4) / kThreads;   // float4 per thread per tile
     static constexpr int kLoadB = BN * (BK / 4) / kThreads;
     static constexpr int kChains = NC * WK;                   // K-order class of this instance
-    static constexpr int kLdsFloats = 2 * (BM + BN) * LDT;
+    static constexpr int kBufs = OVC_F32_BUFS;                // LDS tile buffers (2: one barrier per K tile)
+    static constexpr int kTileFloats = kBufs * (BM + BN) * LDT;
+    static constexpr int kRedFloats = (WK - 1) * NC * BM * BN;    // chain reduction scratch (re-uses the tile buffers)
+    static constexpr int kLdsFloats = kTileFloats > kRedFloats ? kTileFloats : kRedFloats;
     static_assert(WM * WN * WK == 4, "four waves per workgroup");
     static_assert(kChains == 1 || kChains == 4, "K-order classes: one chain or four");
     static_assert(BK % 8 == 0 && (kChains == 1 || BK % 32 == 0), "a K tile holds whole 8-deep groups (four chains: whole 4-group periods)");
     static_assert(kWaveM % 32 == 0 && kWaveN % 32 == 0, "wave tile must be a multiple of 32x32");
     static_assert(kLoadA >= 1 && kLoadB >= 1, "tile too small for 256 loader threads");
-    static_assert((WK - 1) * NC * BM * BN <= kLdsFloats, "chain reduction must fit in the tile buffers");
+
 };
 
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
@@ -241,7 +251,7 @@ __global__ __launch_bounds__(256, (min_waves_per_simd<BM, BN, BK, NC>())) void g
     const int frag_k = (lane >> 5) * 4;
 
     for (int kt = 0; kt < nkt; ++kt) {
-        const int buf = kt & 1;
+        const int buf = Cfg::kBufs == 2 ? (kt & 1) : 0;
         if (kt + 1 < nkt) load_tile(kt + 1);
 
         const float* a_base = lds + buf * kBufFloats + (wm * Cfg::kWaveM + frag_row) * LDT + frag_k;
@@ -275,7 +285,10 @@ __global__ __launch_bounds__(256, (min_waves_per_simd<BM, BN, BK, NC>())) void g
             __builtin_amdgcn_s_setprio(0);
         }
 
-        if (kt + 1 < nkt) store_tile(buf ^ 1);
+        if (kt + 1 < nkt) {
+            if (Cfg::kBufs == 1) __syncthreads();
+            store_tile(Cfg::kBufs == 2 ? (buf ^ 1) : 0);
+        }
         __syncthreads();
     }
 

@@ -23,9 +23,16 @@
 // distinct mod 16 on 16 distinct 4-bank slots, which is what one ds_read_b128 lane group touches).  Operand fragment of
 // the 32x32x16 MFMA: lane l holds row l & 31, k = 8 (l >> 5) .. + 7 -- one ds_read_b128 per plane and k step; A and B use
 // the same lane <-> k map, so every k is summed exactly once.
-// kBufs = 2: double-buffered tiles, one barrier per K tile; kBufs = 1 (large tiles at P = 3, where two buffers would leave
-// one workgroup per CU): the next tile waits in registers and is converted + written after a second barrier.
+// kBufs = 1 (default, see OVC_SPLIT_DB_LIMIT): one LDS tile; the next tile waits in registers and is converted + written after a
+// second barrier.  kBufs = 2: double-buffered tiles, one barrier per K tile.
 #pragma once
+// Double-buffer a tile only when both buffers fit in this many bytes.  0 = never: measured on one box (bench.py --precision
+// f16x3, alternating runs), single-buffered tiles -- half the LDS per workgroup, hence more workgroups of OTHER launches
+// resident beside them -- gave 35.9 / 36.1k captions/s against 34.0 / 34.2k with double buffering up to 80 KB, and 142 against
+// 133-135 TFLOP/s-equivalent kernel-scoped on a lone stream.
+#ifndef OVC_SPLIT_DB_LIMIT
+#define OVC_SPLIT_DB_LIMIT 0
+#endif
 
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -50,7 +57,7 @@ struct SplitConfig {
     static constexpr int kLoadA = BM * (BK / 4) / 256;          // float4 per thread per tile
     static constexpr int kLoadB = BN * (BK / 4) / 256;
     static constexpr int kBufHalves = (BM + BN) * P * LDT;      // one buffer: A planes then B planes
-    static constexpr int kBufs = 2 * kBufHalves * 2 <= 80 * 1024 ? 2 : 1;
+    static constexpr int kBufs = 2 * kBufHalves * 2 <= OVC_SPLIT_DB_LIMIT ? 2 : 1;
     static constexpr int kLdsBytes = kBufs * kBufHalves * 2;
     static constexpr int kProducts = P * (P + 1) / 2;
     static_assert(WM * WN == 4, "four waves per workgroup");
