@@ -13,7 +13,7 @@ from openviic_amd import native
 
 DECODE = [  # (M, N, K, kchains, ksplit, note)
     (1280, 512, 512, 4, 1, "dec cross-q"), (1280, 512, 512, 4, 2, "dec o-proj /2"), (1280, 1536, 512, 4, 1, "dec qkv"),
-    (1280, 2048, 512, 4, 1, "dec ffn1"), (1280, 512, 2048, 4, 4, "dec ffn2 /4"), (1280, 512, 2048, 4, 2, "dec ffn2 /2"),
+    (1280, 2048, 512, 4, 1, "dec ffn1"), (1280, 512, 2048, 4, 4, "dec ffn2 /4"), (1280, 512, 2048, 4, 2, "dec ffn2 /2"), (1280, 512, 2048, 4, 1, "dec ffn2 /1"),
     (1280, 10201, 512, 4, 1, "vocab"), (256, 512, 512, 4, 1, "t=0 proj"), (256, 10201, 512, 4, 1, "t=0 vocab"),
 ]
 ENCODER = [
