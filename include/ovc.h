@@ -174,8 +174,8 @@ typedef struct {
                                          use.  1 / 2 / 3 = OPT-IN split precision: every GEMM of the engine cuts its fp32
                                          operands into that many bf16 planes and contracts them on the 16-bit matrix path
                                          with fp32 accumulation (1, 3 or 6 plane products: "bf16", "bf16x3", "bf16x6");
-                                         4 = two fp16 planes with a scaled residual, 3 products ("f16x3"; operands must
-                                         lie in fp16's range).  K-order classes 101..104.  fp32 in, fp32 out, attention /
+                                         4 = two fp16 planes with a scaled residual, 3 products ("f16x3"; weights must lie
+                                         in fp16's range -- the feature projection takes mode 3, so features need not).  K-order classes 101..104.  fp32 in, fp32 out, attention /
                                          LayerNorm / selection unchanged; results differ from mode 0 in the low-order
                                          bits (3, 4), at ~1e-5 (2) or ~1e-2 (1) relative -- see DESIGN.md for the
                                          measured token-id agreement.                                                  */

@@ -240,6 +240,10 @@ struct Engine {
 
     int gemm(GemmArgs& a) {
         a.kchains = m->precision > 0 ? 100 + m->precision : kchains;   // opt-in split precision: its own K-order classes
+        // fp16 planes cannot hold what lies outside fp16's range.  Weights are checked when the mode is selected, activations
+        // behind a LayerNorm / softmax / ReLU of bounded operands are bounded -- the caller's features are not: their
+        // projection takes the three-plane bf16 class, whose planes have fp32's exponent range.
+        if (m->precision == 4 && gemm_class == 0) a.kchains = 103;
         a.objective = m->tune_objective;
         if (dry) {
             const GemmShape sh{a.M, a.seg_n, a.nseg, a.K1 + a.K2, a.kchains, a.ksplit > 1 ? a.ksplit : 1};

@@ -14,7 +14,8 @@
 //     p0 = f16(x), p1 = f16((x - p0) * 2^11);   a0 b0 in one accumulator, a0 b1 + a1 b0 in a second one that joins
 //     the first with the factor 2^-11 in the epilogue: 22 bits per operand from 3 products (fp16 carries 11 bits where
 //     bf16 carries 8) -- close to the 6-product bf16 mode's accuracy at the 3-product mode's cost.  Operands must lie
-//     inside fp16's range (|x| < 65504); smaller than 6e-5 they keep an absolute accuracy of 3e-11.
+//     inside fp16's range (|x| < 65504: the engine checks the weights when the mode is selected and gives the projection of the
+//     caller's features to MODE 3, whose planes have fp32's exponent range); smaller than 6e-5 they keep an absolute accuracy of 3e-11.
 // The small terms are accumulated first.  One summation chain over k per output (16-deep MFMA steps in order, products
 // in the fixed order above), whatever the tiling: all tilings of one P give the same bits, so the tuner may pick freely,
 // exactly as inside the fp32 K-order classes (gemm.hip).

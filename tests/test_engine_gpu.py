@@ -354,7 +354,8 @@ def test_split_precision_modes_are_opt_in_deterministic_and_measured(mode, produ
                 forced += 1
         finally:
             lib.ovc_debug_force_gemm_tiling(-1)
-        assert forced == 7 and all(s[4] == cls for s in engine.gemm_shapes(48, 50, 5))
+        classes = {s[4] for s in engine.gemm_shapes(48, 50, 5)}
+        assert forced == 7 and classes == ({cls, 103} if mode == "f16x3" else {cls})    # f16x3: features through bf16 planes
     same_fp32 = (ids == ref_ids).all(dim=1).float().mean().item()
     same_gold = float((ids.cpu().numpy() == g["B48_k5_ids"]).all(axis=1).mean())
     both = (ids == ref_ids).all(dim=1)
@@ -363,6 +364,22 @@ def test_split_precision_modes_are_opt_in_deterministic_and_measured(mode, produ
           "reference goldens on {:.1%}; max |dlogp| on identical captions {:.2e}".format(mode, products, same_fp32, same_gold, dlp))
     assert same_fp32 >= min_same
     assert torch.isfinite(lp).all() and ids.min() >= 0 and ids.max() < FULL["V"]
+    if mode == "f16x3":
+        # features far outside fp16's range (the projection runs on bf16 planes) decode to finite scores; weights outside
+        # it are refused when the mode is selected
+        with torch.no_grad():
+            big_ids, big_lp = engine.beam_search(x * 3.0e5, None, 48, 5)
+        assert torch.isfinite(big_lp).all() and big_ids.min() >= 0
+        w = model.encoder.layers[0].pwff.fc1.weight
+        keep = w.detach().clone()
+        try:
+            with torch.no_grad():
+                w[0, 0] = 1.0e5
+            with pytest.raises(native.OvcError):
+                CaptionEngine(model, precision="f16x3")
+        finally:
+            with torch.no_grad():
+                w.copy_(keep)
 
 
 def test_hipgraph_replay_matches_plain_launches():
