@@ -313,6 +313,29 @@ def test_results_do_not_depend_on_the_gemm_tiling():
     assert t == 45          # 17 fp32 instances + 28 of the split-precision classes (no-ops here: another class is never used)
 
 
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_f16x3_mode_decodes_the_reference_goldens_of_every_architecture(variant):
+    """The opt-in two-plane fp16 mode on every architecture's full-size golden (beam 5, B = 16 and 48): ids exact wherever
+    the reference's own decision margins exceed fp32 noise -- the bar the fp32 path is held to -- and log-probabilities
+    inside the north-star tolerance.  (fp32 stays the parity mode; this pins what DESIGN.md section 5a reports.)"""
+    from openviic_amd.engine import CaptionEngine
+    g = golden("g2_full_%s.npz" % variant)
+    engine = None
+    with torch.no_grad():
+        for B in (16, 48):
+            cfg, vocab, sd, feats, boxes = full_case(variant, B)
+            if engine is None:
+                engine = CaptionEngine(device_model(cfg, vocab, sd), precision="f16x3")
+            ids, logp = engine.beam_search(feats.cuda(), None if boxes is None else boxes.cuda(), B, 5)
+            p = "B%d_k5_" % B
+            decided = assert_ids_match_where_decided(ids.cpu().numpy(), g[p + "ids"], g[p + "gap"], g[p + "inner_gap"], MARGIN,
+                                                     variant + " f16x3 " + p)
+            same = (ids.cpu().numpy() == g[p + "ids"]).all(axis=1)
+            print("[split precision] f16x3 {} {}: decided {}/{}, identical to the reference {}/{}".format(
+                variant, p, int(decided.sum()), B, int(same.sum()), B))
+            _logp_close(logp.cpu().numpy()[same], g[p + "logp"][same], variant + " f16x3 " + p + "logp")
+
+
 SPLIT_MODES = [("bf16x6", 6, 0.9), ("f16x3", 3, 0.9), ("bf16x3", 3, 0.6), ("bf16", 1, 0.0)]
 
 
