@@ -126,7 +126,13 @@ int ovc_beam_select(const float* logp, const float* running, const float* alive,
  * Engine level: the fused hot path  (models/base_transformer.py:45-53 and everything below it)
  * ==================================================================================== */
 
-typedef struct { const float* w; const float* b; } ovc_lin;      /* nn.Linear  weight, bias  */
+typedef struct {
+    const float* w; const float* b;   /* nn.Linear weight [out, in], bias [out] or NULL                       */
+    const void* planes;               /* split-precision modes only (ovc_model::precision > 0), optional: `w` cut by
+                                         ovc_split_weight in that mode (the feature projection of mode 4: mode 3) -- the
+                                         engine's GEMMs then read the planes instead of cutting w in every workgroup.
+                                         Same bits either way.  The host re-cuts them when it changes w.  NULL = none. */
+} ovc_lin;
 typedef struct { const float* g; const float* b; } ovc_norm;     /* nn.LayerNorm weight, bias */
 
 typedef struct {
@@ -166,6 +172,7 @@ typedef struct {
     const float* word_emb;            /* decoder.word_emb.components.weight [V, d]          */
     const float* pos_emb;             /* decoder.pos_emb.weight [max_len+1, d]              */
     const float* fc;                  /* decoder.fc.weight [V, d] (no bias)                 */
+    const void*  fc_planes;           /* its planes (see ovc_lin::planes) or NULL           */
     int32_t tune_objective;           /* which GEMM tuning table the engine consults: 0 / 1 = tilings measured in
                                          isolation, c > 1 = measured with c co-running copies (ovc_gemm_tune_objective)
                                          -- for hosts that keep several batches in flight on different streams.
@@ -251,7 +258,8 @@ const char* ovc_profile_kernel_name(int tiling);   /* "" past the last tiling */
  * segments of seg_n rows; ksplit > 1 needs nseg == 1) and remembers the fastest for this process; later GEMMs of
  * that shape and class use it, and shapes whose M is within a factor of two of a measured one borrow its entry.
  * scratch: >= 4*(M*K + nseg*seg_n*K + ksplit*M*nseg*seg_n) + 64 bytes of device memory (contents are used as
- * operands).  SYNCHRONISES the stream -- set-up time only.  Thread-safe. */
+ * operands); for the split-precision classes, nseg * ovc_split_weight_bytes(seg_n, K, kchains - 100) more bytes make the
+ * measurement use pre-cut weight planes (what the engine runs when ovc_lin::planes are set).  SYNCHRONISES the stream -- set-up time only.  Thread-safe. */
 int ovc_gemm_tune(int M, int seg_n, int nseg, int K, int kchains, int ksplit, void* scratch, size_t scratch_bytes,
                   ovc_stream stream);
 long ovc_gemm_tune_calls(void);        /* measurements run so far in this process */
@@ -288,6 +296,15 @@ int ovc_graph_cache_size(void);
 int ovc_debug_force_gemm_tiling(int tiling);
 int ovc_debug_linear_tiling(const float* x, int K, const float* W, const float* bias, float* y, int M, int N,
                             int tiling, int ksplit, int iters, ovc_stream stream);
+
+/* Split-precision modes: a weight W [N, K] (K a multiple of 16) cut ONCE into the 16-bit planes of `mode` (1..4, as
+ * ovc_model::precision), stored in MFMA-operand order so that the GEMM's waves read them straight from memory instead of
+ * cutting W again in every workgroup.  ovc_split_weight_bytes = size of `planes` (0 = invalid arguments); the planes hold the
+ * same bits the kernel would cut, so results do not change.  ovc_debug_linear_planes = ovc_debug_linear_tiling on them. */
+size_t ovc_split_weight_bytes(int N, int K, int mode);
+int ovc_split_weight(const float* W, int N, int K, int mode, void* planes, ovc_stream stream);
+int ovc_debug_linear_planes(const float* x, int K, const float* W, const void* planes, const float* bias, float* y,
+                            int M, int N, int tiling, int ksplit, int iters, ovc_stream stream);
 /* `iters` back-to-back launches of y = x W^T + bias (x [M,K], W [N,K]) with no host work between. */
 int ovc_debug_repeat_linear(const float* x, int K, const float* W, const float* bias, float* y,
                             int M, int N, int iters, ovc_stream stream);

@@ -36,6 +36,8 @@ struct GemmSegment {
     const float* bias;   // [seg_n] or nullptr
     float* C;            // [M, seg_n] with row stride ldc
     const float* A2;     // this segment's own second input block [M, K2] (row stride lda2), or nullptr = GemmArgs::A2
+    const void* Wp;      // split-precision classes only: W cut into 16-bit planes in MFMA-fragment order (ovc_split_weight),
+                         // read by each wave straight from memory -- or nullptr: the kernel cuts W itself, through LDS
 };
 
 struct GemmArgs {

@@ -238,6 +238,11 @@ struct Engine {
     int kchains = 1;                                 // K-order class of the GEMMs issued next (set per call site group)
     std::vector<GemmShape>* dry = nullptr;           // shape enumeration: record every GEMM, launch nothing
 
+    // A weight segment; in the split-precision modes with the weight's pre-cut planes (ovc_lin::planes) when the host built them
+    GemmSegment seg(const ovc_lin& l, float* C, const float* A2 = nullptr) const {
+        return GemmSegment{l.w, l.b, C, A2, m->precision > 0 ? l.planes : nullptr};
+    }
+
     int gemm(GemmArgs& a) {
         a.kchains = m->precision > 0 ? 100 + m->precision : kchains;   // opt-in split precision: its own K-order classes
         // fp16 planes cannot hold what lies outside fp16's range.  Weights are checked when the mode is selected, activations
@@ -280,7 +285,7 @@ struct Engine {
         GemmArgs a{};
         a.A1 = x; a.lda1 = K; a.K1 = K; a.M = M; a.seg_n = N; a.nseg = 1; a.ldc = N;
         a.R = residual; a.ldr = N; a.act = act;
-        a.seg[0] = GemmSegment{l.w, l.b, y};
+        a.seg[0] = seg(l, y);
         return gemm(a);
     }
 
@@ -299,7 +304,7 @@ struct Engine {
         GemmArgs a{};
         a.A1 = x; a.lda1 = K; a.K1 = K; a.M = M; a.seg_n = d; a.nseg = 1; a.ldc = d;
         a.ksplit = split; a.part_stride = (long)M * d;
-        a.seg[0] = GemmSegment{l.w, nullptr, part};
+        a.seg[0] = seg(l, part); a.seg[0].bias = nullptr;     // raw partial products: bias applied by the consumer
         TRY(gemm(a));
         if (dry) return OVC_OK;
         return ovc_layer_norm_parts(part, split, a.part_stride, l.b, residual, ln.g, ln.b, zero_rows, m->ln_eps, out, M, d, stream);
@@ -312,12 +317,12 @@ struct Engine {
         GemmArgs a{};
         a.A1 = queries; a.lda1 = d; a.K1 = d; a.A2 = x; a.lda2 = d; a.K2 = d;
         a.M = M; a.seg_n = d; a.nseg = 2; a.ldc = d;
-        a.seg[0] = GemmSegment{w.aoa_i.w, w.aoa_i.b, info};
-        a.seg[1] = GemmSegment{w.aoa_g.w, w.aoa_g.b, gate};
+        a.seg[0] = seg(w.aoa_i, info);
+        a.seg[1] = seg(w.aoa_g, gate);
         if (d % 64) {   // segments must align with tiles: fall back to two launches
             a.nseg = 1;
             TRY(gemm(a));
-            a.seg[0] = GemmSegment{w.aoa_g.w, w.aoa_g.b, gate};
+            a.seg[0] = seg(w.aoa_g, gate);
             TRY(gemm(a));
         } else {
             TRY(gemm(a));
@@ -363,9 +368,9 @@ int run_encoder_layers(Engine& e, Workspace& w, int B, int N) {
         const ovc_mha& at = m->enc[l].att;
         GemmArgs a{};
         a.A1 = x; a.lda1 = d; a.K1 = d; a.M = BN; a.seg_n = hk; a.nseg = 3; a.ldc = hk;
-        a.seg[0] = GemmSegment{at.q.w, at.q.b, w.eq};
-        a.seg[1] = GemmSegment{at.k.w, at.k.b, w.ek};
-        a.seg[2] = GemmSegment{at.v.w, at.v.b, w.ev};
+        a.seg[0] = e.seg(at.q, w.eq);
+        a.seg[1] = e.seg(at.k, w.ek);
+        a.seg[2] = e.seg(at.v, w.ev);
         TRY(e.gemm(a));
         const int mem = at.m_k ? m->memory : 0;
         RUN(ovc_attention(w.eq, w.ek, w.ev, B, N, N, m->heads, m->d_k, m->d_v, w.enc_mask, N, 0,
@@ -403,8 +408,8 @@ int project_cross_kv(Engine& e, Workspace& w, int B, int N) {
             for (int l = l0; l < L && ns + 2 <= OVC_MAX_SEGMENTS; ++l) {
                 const ovc_mha& at = m->dec[l].cross_att;
                 const size_t off = ((size_t)l * lv + lvl) * BN * hk;
-                a.seg[ns++] = GemmSegment{at.k.w, at.k.b, w.kx + off};
-                a.seg[ns++] = GemmSegment{at.v.w, at.v.b, w.vx + off};
+                a.seg[ns++] = e.seg(at.k, w.kx + off);
+                a.seg[ns++] = e.seg(at.v, w.vx + off);
             }
             a.nseg = ns;
             TRY(e.gemm(a));
@@ -437,9 +442,9 @@ int run_decode_step(Engine& e, Workspace& w, int B, int N, int k, int t, int ret
         float* vc = w.vc + (size_t)l * T * R * hv;
         GemmArgs a{};
         a.A1 = x; a.lda1 = d; a.K1 = d; a.M = rows; a.seg_n = hk; a.nseg = 3; a.ldc = hk;
-        a.seg[0] = GemmSegment{dl.self_att.q.w, dl.self_att.q.b, w.q};
-        a.seg[1] = GemmSegment{dl.self_att.k.w, dl.self_att.k.b, kc + (size_t)t * R * hk};
-        a.seg[2] = GemmSegment{dl.self_att.v.w, dl.self_att.v.b, vc + (size_t)t * R * hv};
+        a.seg[0] = e.seg(dl.self_att.q, w.q);
+        a.seg[1] = e.seg(dl.self_att.k, kc + (size_t)t * R * hk);
+        a.seg[2] = e.seg(dl.self_att.v, vc + (size_t)t * R * hv);
         TRY(e.gemm(a));
         DecodeSelfArgs sa{};
         sa.q = w.q; sa.ldq = hk; sa.kcache = kc; sa.vcache = vc; sa.pos_stride = (size_t)R * hk; sa.ldkv = hk;
@@ -467,7 +472,7 @@ int run_decode_step(Engine& e, Workspace& w, int B, int N, int k, int t, int ret
                 GemmArgs o{};
                 o.A1 = w.att; o.lda1 = hv; o.K1 = hv; o.M = lv * rows; o.seg_n = d; o.nseg = 1; o.ldc = d;
                 o.R = w.x1; o.ldr = d; o.res_mod = rows;
-                o.seg[0] = GemmSegment{dl.cross_att.o.w, dl.cross_att.o.b, w.ymesh};
+                o.seg[0] = e.seg(dl.cross_att.o, w.ymesh);
                 TRY(e.gemm(o));
                 RUN(ovc_layer_norm(w.ymesh, nullptr, dl.cross_att.ln.g, dl.cross_att.ln.b, nullptr, 0, nullptr, m->ln_eps,
                                    w.enc_att, lv * rows, d, s));
@@ -487,7 +492,7 @@ int run_decode_step(Engine& e, Workspace& w, int B, int N, int k, int t, int ret
                 g.M = rows; g.seg_n = d; g.ldc = d;
                 const bool fused = d % 64 == 0 && lv <= OVC_MAX_SEGMENTS;
                 for (int lvl = 0; lvl < lv; ++lvl) {
-                    GemmSegment seg{dl.alpha[lvl].w, dl.alpha[lvl].b, w.alpha + lvl * nrd, w.enc_att + lvl * nrd};
+                    const GemmSegment seg = e.seg(dl.alpha[lvl], w.alpha + lvl * nrd, w.enc_att + lvl * nrd);
                     if (fused) { g.seg[lvl] = seg; continue; }
                     g.seg[0] = seg; g.nseg = 1;
                     TRY(e.gemm(g));
@@ -511,7 +516,7 @@ int run_decode_step(Engine& e, Workspace& w, int B, int N, int k, int t, int ret
     {
         GemmArgs g{};
         g.A1 = x; g.lda1 = d; g.K1 = d; g.M = rows; g.seg_n = m->vocab; g.nseg = 1; g.ldc = ldv;
-        g.seg[0] = GemmSegment{m->fc, nullptr, w.logits};
+        g.seg[0] = GemmSegment{m->fc, nullptr, w.logits, nullptr, m->precision > 0 ? m->fc_planes : nullptr};
         TRY(e.gemm(g));
     }
     BeamSelectArgs bs{};
@@ -538,7 +543,7 @@ int run_decode_step(Engine& e, Workspace& w, int B, int N, int k, int t, int ret
 
 }  // namespace
 
-extern "C" int ovc_abi_version(void) { return 4; }
+extern "C" int ovc_abi_version(void) { return 5; }
 
 extern "C" const char* ovc_build_info(void) {
     return "libovc gfx950 (CDNA4) fp32: v_mfma_f32_32x32x2_f32 GEMM + attention, HIP " __DATE__;

@@ -426,26 +426,31 @@ int launch_config(const GemmArgs& a, hipStream_t stream, const GemmLaunchOpts& o
     return OVC_OK;
 }
 
-template <int BM, int BN, int WM, int WN, int BK, int MODE>
+template <int BM, int BN, int WM, int WN, int BK, int MODE, bool WD = false>
 int launch_split_config(const GemmArgs& a, hipStream_t stream, const GemmLaunchOpts& opts) {
-    using Cfg = SplitConfig<BM, BN, WM, WN, BK, MODE>;
+    using Cfg = SplitConfig<BM, BN, WM, WN, BK, MODE, WD>;
+    if constexpr (!WD) {             // pre-cut weights on every segment: the instance that reads them straight from memory
+        bool planes = (a.K1 + a.K2) % BK == 0 && a.K1 % BK == 0;   // whole K tiles only: the planes have no zero tail to read
+        for (int s = 0; s < a.nseg; ++s) planes = planes && a.seg[s].Wp != nullptr;
+        if (planes) return launch_split_config<BM, BN, WM, WN, BK, MODE, true>(a, stream, opts);
+    }
     const int tiles_m = (a.M + BM - 1) / BM;
     const int tiles_n = (a.seg_n + BN - 1) / BN;
     const int grid = tiles_m * tiles_n * a.nseg;
     const size_t lds_bytes = Cfg::kLdsBytes;
     static std::once_flag attr_once;
     std::call_once(attr_once, [&] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_split_mfma<BM, BN, WM, WN, BK, MODE>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_split_mfma<BM, BN, WM, WN, BK, MODE, WD>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     });
     int group_m, xcd_pm;
     tile_order(a, tiles_m, tiles_n, &group_m, &xcd_pm);
     const dim3 grid3(grid, a.ksplit > 1 ? a.ksplit : 1, opts.copies > 1 ? opts.copies : 1);
     if (opts.start && opts.stop)
-        hipExtLaunchKernelGGL((gemm_split_mfma<BM, BN, WM, WN, BK, MODE>), grid3, dim3(256), (uint32_t)lds_bytes, stream,
+        hipExtLaunchKernelGGL((gemm_split_mfma<BM, BN, WM, WN, BK, MODE, WD>), grid3, dim3(256), (uint32_t)lds_bytes, stream,
                               opts.start, opts.stop, 0, a, tiles_m, tiles_n, group_m, xcd_pm);
     else
-        hipLaunchKernelGGL((gemm_split_mfma<BM, BN, WM, WN, BK, MODE>), grid3, dim3(256), lds_bytes, stream, a, tiles_m, tiles_n, group_m, xcd_pm);
+        hipLaunchKernelGGL((gemm_split_mfma<BM, BN, WM, WN, BK, MODE, WD>), grid3, dim3(256), lds_bytes, stream, a, tiles_m, tiles_n, group_m, xcd_pm);
     OVC_RETURN_IF_LAUNCH_FAILED();
     return OVC_OK;
 }
@@ -550,6 +555,8 @@ bool tiling_fits(const GemmArgs& a, int t) {
 
 }  // namespace
 
+extern "C" size_t ovc_split_weight_bytes(int N, int K, int mode);
+
 extern "C" int ovc_debug_force_gemm_tiling(int tiling) {
     if (tiling < -1 || tiling >= kNumTilings) return OVC_EINVAL;
     g_forced_tiling.store(tiling);
@@ -643,7 +650,15 @@ extern "C" int ovc_gemm_tune(int M, int seg_n, int nseg, int K, int kchains, int
     GemmArgs a{};
     a.A1 = A; a.lda1 = K; a.K1 = K; a.M = M; a.seg_n = seg_n; a.nseg = nseg; a.ldc = seg_n; a.kchains = kchains;
     if (ksplit > 1) { a.ksplit = ksplit; a.part_stride = (long)nc; }
-    for (int s = 0; s < nseg; ++s) a.seg[s] = GemmSegment{W + (size_t)s * seg_n * K, nullptr, C + (size_t)s * M * seg_n, nullptr};
+    for (int s = 0; s < nseg; ++s) a.seg[s] = GemmSegment{W + (size_t)s * seg_n * K, nullptr, C + (size_t)s * M * seg_n, nullptr, nullptr};
+    // split-precision classes: when the scratch buffer has room behind the outputs, rank the instances that read pre-cut
+    // weight planes (what the engine runs when the host supplies ovc_lin::planes); any bit pattern will do for a timing
+    if (kchains > kSplitClass && (K & 15) == 0) {
+        const size_t plane_floats = (ovc_split_weight_bytes(seg_n, K, kchains - kSplitClass) + 3) / 4;
+        float* P = C + (((size_t)ksplit * nc + 3) & ~(size_t)3);
+        if ((size_t)(P - A) + (size_t)nseg * plane_floats <= scratch_bytes / sizeof(float))
+            for (int s = 0; s < nseg; ++s) a.seg[s].Wp = P + (size_t)s * plane_floats;
+    }
     hipStream_t st = ovc_hip_stream(stream);
     hipEvent_t e0, e1;
     if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return OVC_ELAUNCH;
@@ -712,6 +727,63 @@ extern "C" int ovc_debug_repeat_linear(const float* x, int K, const float* W, co
     a.seg[0] = GemmSegment{W, bias, y, nullptr};
     for (int i = 0; i < iters; ++i) {
         const int rc = ovc_gemm_launch(a, ovc_hip_stream(stream), GemmLaunchOpts{});
+        if (rc != OVC_OK) return rc;
+    }
+    return OVC_OK;
+}
+
+namespace {
+// W [N, K] fp32 -> 16-bit planes in MFMA-fragment order (gemm_split.h, WD): block j = 32 rows of W, step s = 16 columns;
+// lane l of a wave holds row 32 j + (l & 31), columns 16 s + 8 (l >> 5) .. + 7.  Rows past N are zero.
+template <int MODE>
+__global__ __launch_bounds__(64) void split_weight_kernel(const float* __restrict__ W, int N, int K, u32x4* __restrict__ out) {
+    constexpr int P = split_planes(MODE);
+    const int lane = threadIdx.x, j = blockIdx.y, s = blockIdx.x, steps = K >> 4;
+    const int row = 32 * j + (lane & 31), col = 16 * s + 8 * (lane >> 5);
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = row < N ? W[(size_t)row * K + col + e] : 0.f;
+    unsigned int pk[4][P];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) split_pair<MODE>(v[2 * q], v[2 * q + 1], pk[q]);
+#pragma unroll
+    for (int pl = 0; pl < P; ++pl)
+        out[(((size_t)j * steps + s) * P + pl) * 64 + lane] = u32x4{pk[0][pl], pk[1][pl], pk[2][pl], pk[3][pl]};
+}
+}  // namespace
+
+// Bytes of the planes of a [N, K] weight in split-precision mode `mode` (1..4); 0 = invalid.
+extern "C" size_t ovc_split_weight_bytes(int N, int K, int mode) {
+    if (N <= 0 || K <= 0 || (K & 15) || mode < 1 || mode > 4) return 0;
+    return (size_t)((N + 31) / 32) * (K >> 4) * split_planes(mode) * 64 * 16;
+}
+
+extern "C" int ovc_split_weight(const float* W, int N, int K, int mode, void* planes, ovc_stream stream) {
+    if (!W || !planes || !ovc_split_weight_bytes(N, K, mode) || !ovc_aligned16(planes)) return OVC_EINVAL;
+    const dim3 grid(K >> 4, (N + 31) / 32);
+    u32x4* out = reinterpret_cast<u32x4*>(planes);
+    switch (mode) {
+        case 1: hipLaunchKernelGGL(split_weight_kernel<1>, grid, dim3(64), 0, ovc_hip_stream(stream), W, N, K, out); break;
+        case 2: hipLaunchKernelGGL(split_weight_kernel<2>, grid, dim3(64), 0, ovc_hip_stream(stream), W, N, K, out); break;
+        case 3: hipLaunchKernelGGL(split_weight_kernel<3>, grid, dim3(64), 0, ovc_hip_stream(stream), W, N, K, out); break;
+        default: hipLaunchKernelGGL(split_weight_kernel<4>, grid, dim3(64), 0, ovc_hip_stream(stream), W, N, K, out); break;
+    }
+    OVC_RETURN_IF_LAUNCH_FAILED();
+    return OVC_OK;
+}
+
+// ovc_debug_linear_tiling with pre-cut weights (`planes` from ovc_split_weight, mode of the tiling's class).
+extern "C" int ovc_debug_linear_planes(const float* x, int K, const float* W, const void* planes, const float* bias, float* y,
+                                       int M, int N, int tiling, int ksplit, int iters, ovc_stream stream) {
+    if (tiling < 0 || tiling >= kNumTilings || !kTilings[tiling].planes || !x || !W || !planes || !y || iters < 1) return OVC_EINVAL;
+    GemmArgs a{};
+    a.A1 = x; a.lda1 = K; a.K1 = K; a.M = M; a.seg_n = N; a.nseg = 1; a.ldc = N; a.kchains = tiling_chains(tiling);
+    a.seg[0] = GemmSegment{W, ksplit > 1 ? nullptr : bias, y, nullptr, planes};
+    if (ksplit > 1) { a.ksplit = ksplit; a.part_stride = (long)M * N; }
+    GemmLaunchOpts opts{};
+    opts.forced_tiling = tiling;
+    for (int i = 0; i < iters; ++i) {
+        const int rc = ovc_gemm_launch(a, ovc_hip_stream(stream), opts);
         if (rc != OVC_OK) return rc;
     }
     return OVC_OK;

@@ -47,7 +47,12 @@ constexpr bool split_is_half(int mode) { return mode == 4; }
 constexpr int split_planes(int mode) { return mode == 4 ? 2 : mode; }
 constexpr float kHalfResidualScale = 2048.f;      // 2^11: the residual of an 11-bit plane, back in fp16's normal range
 
-template <int BM, int BN, int WM, int WN, int BK, int MODE>
+// WD ("W direct"): the weights come pre-cut (ovc_split_weight) in fragment order -- for (32-row block j of W, 16-deep step s,
+// plane p) the 64 lanes' 16-byte MFMA operands are contiguous, [(j S + s) P + p][lane] with S = K / 16 -- and every wave loads
+// the operands of its own columns straight into registers one K tile ahead: W costs no conversion, no LDS space and no LDS
+// bandwidth (the 64x64 instances are bound by ds_read_b128 otherwise), and the planes are as many bytes as the fp32 weights
+// (two planes) or 1.5x (three).
+template <int BM, int BN, int WM, int WN, int BK, int MODE, bool WD = false>
 struct SplitConfig {
     static constexpr int P = split_planes(MODE);
     static constexpr bool kHalf = split_is_half(MODE);
@@ -57,7 +62,7 @@ struct SplitConfig {
     static constexpr int TM = kWaveM / 32, TN = kWaveN / 32;
     static constexpr int kLoadA = BM * (BK / 4) / 256;          // float4 per thread per tile
     static constexpr int kLoadB = BN * (BK / 4) / 256;
-    static constexpr int kBufHalves = (BM + BN) * P * LDT;      // one buffer: A planes then B planes
+    static constexpr int kBufHalves = (BM + (WD ? 0 : BN)) * P * LDT;   // one buffer: A planes then (unless WD) B planes
     static constexpr int kBufs = 2 * kBufHalves * 2 <= OVC_SPLIT_DB_LIMIT ? 2 : 1;
     static constexpr int kLdsBytes = kBufs * kBufHalves * 2;
     static constexpr int kProducts = P * (P + 1) / 2;
@@ -99,9 +104,9 @@ __device__ __forceinline__ f32x16 split_mma(const u32x4& a, const u32x4& b, cons
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
-template <int BM, int BN, int WM, int WN, int BK, int MODE>
+template <int BM, int BN, int WM, int WN, int BK, int MODE, bool WD = false>
 __global__ __launch_bounds__(256) void gemm_split_mfma(GemmArgs p, int tiles_m, int tiles_n_per_seg, int group_m, int xcd_pm) {
-    using Cfg = SplitConfig<BM, BN, WM, WN, BK, MODE>;
+    using Cfg = SplitConfig<BM, BN, WM, WN, BK, MODE, WD>;
     constexpr int P = Cfg::P;
     constexpr int LDT = Cfg::LDT;
     constexpr int kVecPerRow = BK / 4;
@@ -164,6 +169,18 @@ __global__ __launch_bounds__(256) void gemm_split_mfma(GemmArgs p, int tiles_m, 
 #pragma unroll
         for (int i = 0; i < Cfg::kLoadB; ++i) off_w[i] = ((n0 + tid / kVecPerRow + i * kRowsPerPass) * K + kq * 4) * 4;
     }
+    // WD: this wave's own operands of the next K tile, [16-deep step][plane][column tile]
+    u32x4 b_next[BK / 16][P][Cfg::TN], b_cur[BK / 16][P][Cfg::TN];
+    // (column blocks past the weight's last 32-row block are clamped onto it: their outputs are never stored, and the planes end there)
+    const u32x4* wp_lane[Cfg::TN];
+    if (WD) {
+        const size_t steps = (size_t)(K >> 4);
+        const int last_block = ((p.seg_n + 31) >> 5) - 1;
+#pragma unroll
+        for (int j = 0; j < Cfg::TN; ++j)
+            wp_lane[j] = reinterpret_cast<const u32x4*>(p.seg[seg].Wp) +
+                         ((size_t)min(((n0 + wn * Cfg::kWaveN) >> 5) + j, last_block) * steps * P) * 64 + lane;
+    }
     auto load_tile = [&](int kt) {
         const int k0 = kbase + kt * BK;
         const bool second = k0 >= p.K1;
@@ -180,9 +197,20 @@ __global__ __launch_bounds__(256) void gemm_split_mfma(GemmArgs p, int tiles_m, 
             for (int i = 0; i < Cfg::kLoadA; ++i)
                 stage_a[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_a2, off_a2[i], (k0 - p.K1) * 4, 0));
         }
+        if (WD) {
+            const size_t steps = (size_t)(K >> 4);
 #pragma unroll
-        for (int i = 0; i < Cfg::kLoadB; ++i)
-            stage_b[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, off_w[i], k0 * 4, 0));
+            for (int ks = 0; ks < BK / 16; ++ks)
+#pragma unroll
+                for (int pl = 0; pl < P; ++pl)
+#pragma unroll
+                    for (int j = 0; j < Cfg::TN; ++j)
+                        b_next[ks][pl][j] = wp_lane[j][((size_t)((k0 >> 4) + ks) * P + pl) * 64];
+        } else {
+#pragma unroll
+            for (int i = 0; i < Cfg::kLoadB; ++i)
+                stage_b[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, off_w[i], k0 * 4, 0));
+        }
     };
     // fp32 registers -> P bf16 planes in LDS (8 bytes per plane and float4)
     auto store_tile = [&](int buf) {
@@ -206,15 +234,24 @@ __global__ __launch_bounds__(256) void gemm_split_mfma(GemmArgs p, int tiles_m, 
             for (int pl = 0; pl < P; ++pl)
                 *reinterpret_cast<u32x2*>(a_lds + (pl * BM + row) * LDT + kq * 4) = u32x2{lo[pl], hi[pl]};
         }
+        if (!WD) {
 #pragma unroll
-        for (int i = 0; i < Cfg::kLoadB; ++i) {
-            const int row = tid / kVecPerRow + i * kRowsPerPass;
-            unsigned int lo[P], hi[P];
-            split_pair<MODE>(stage_b[i][0], stage_b[i][1], lo);
-            split_pair<MODE>(stage_b[i][2], stage_b[i][3], hi);
+            for (int i = 0; i < Cfg::kLoadB; ++i) {
+                const int row = tid / kVecPerRow + i * kRowsPerPass;
+                unsigned int lo[P], hi[P];
+                split_pair<MODE>(stage_b[i][0], stage_b[i][1], lo);
+                split_pair<MODE>(stage_b[i][2], stage_b[i][3], hi);
 #pragma unroll
-            for (int pl = 0; pl < P; ++pl)
-                *reinterpret_cast<u32x2*>(b_lds + (pl * BN + row) * LDT + kq * 4) = u32x2{lo[pl], hi[pl]};
+                for (int pl = 0; pl < P; ++pl)
+                    *reinterpret_cast<u32x2*>(b_lds + (pl * BN + row) * LDT + kq * 4) = u32x2{lo[pl], hi[pl]};
+            }
+        } else {
+#pragma unroll
+            for (int ks = 0; ks < BK / 16; ++ks)
+#pragma unroll
+                for (int pl = 0; pl < P; ++pl)
+#pragma unroll
+                    for (int j = 0; j < Cfg::TN; ++j) b_cur[ks][pl][j] = b_next[ks][pl][j];
         }
     };
 
@@ -251,7 +288,7 @@ __global__ __launch_bounds__(256) void gemm_split_mfma(GemmArgs p, int tiles_m, 
                     a[pl][i] = *reinterpret_cast<const u32x4*>(a_base + (pl * BM + i * 32) * LDT + ks * 16);
 #pragma unroll
                 for (int j = 0; j < Cfg::TN; ++j)
-                    b[pl][j] = *reinterpret_cast<const u32x4*>(b_base + (pl * BN + j * 32) * LDT + ks * 16);
+                    b[pl][j] = WD ? b_cur[ks][pl][j] : *reinterpret_cast<const u32x4*>(b_base + (pl * BN + j * 32) * LDT + ks * 16);
             }
             __builtin_amdgcn_s_setprio(1);
             // plane products, smallest weight first: (pa, pb) with pa + pb = P - 1, ..., 0

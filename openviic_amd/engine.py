@@ -35,28 +35,61 @@ def _p(t):
     return t.data_ptr()
 
 
-def _lin(dst, linear):
+def _lin(dst, linear, planes=None, mode=0):
+    """Pointer pair of an nn.Linear; in a split-precision mode also the weight's pre-cut planes (``planes`` collects
+    (weight, version, buffer, mode) so that a changed weight is cut again before the next call)."""
     dst.w = _p(linear.weight.detach())
     dst.b = _p(linear.bias.detach()) if linear.bias is not None else None
+    if planes is not None and mode and linear.weight.shape[1] % 16 == 0:
+        dst.planes = planes.add(linear.weight, mode)
+
+
+class _WeightPlanes:
+    """Pre-cut 16-bit planes of the GEMM weights for a split-precision engine (``ovc_split_weight``): one device buffer per
+    weight, re-cut when the weight's version counter moved (optimizer step, ``load_state_dict``, ``copy_``)."""
+
+    def __init__(self, lib):
+        self.lib, self.entries, self.lock = lib, [], threading.Lock()
+
+    def add(self, weight, mode):
+        n, k = weight.shape
+        buf = torch.empty(self.lib.ovc_split_weight_bytes(n, k, mode), dtype=torch.uint8, device=weight.device)
+        self.entries.append([weight, -1, buf, mode])
+        return buf.data_ptr()
+
+    def refresh(self, force=False):
+        """Cut again what changed (``force``: everything -- for weights modified behind the version counter, e.g. through
+        ``.data``).  Other streams may decode with these buffers, so a re-cut ends with a stream synchronisation."""
+        with self.lock:
+            stale = [e for e in self.entries if force or e[0]._version != e[1]]
+            for entry in stale:
+                weight, _, buf, mode = entry
+                n, k = weight.shape
+                check(self.lib.ovc_split_weight(_p(weight.detach()), n, k, mode, buf.data_ptr(), native.stream_handle()),
+                      "ovc_split_weight")
+                entry[1] = weight._version
+            if stale:
+                torch.cuda.current_stream().synchronize()
 
 
 def _norm(dst, ln):
     dst.g, dst.b = _p(ln.weight.detach()), _p(ln.bias.detach())
 
 
-def _mha(dst, mha, keep):
+def _mha(dst, mha, keep, planes=None, mode=0):
     att = mha.attention
-    _lin(dst.q, att.fc_q); _lin(dst.k, att.fc_k); _lin(dst.v, att.fc_v); _lin(dst.o, att.fc_o)
+    for d, fc in ((dst.q, att.fc_q), (dst.k, att.fc_k), (dst.v, att.fc_v), (dst.o, att.fc_o)):
+        _lin(d, fc, planes, mode)
     _norm(dst.ln, mha.layer_norm)
     if mha.use_aoa:
-        _lin(dst.aoa_i, mha.informative_attention)
-        _lin(dst.aoa_g, mha.gated_attention)
+        _lin(dst.aoa_i, mha.informative_attention, planes, mode)
+        _lin(dst.aoa_g, mha.gated_attention, planes, mode)
     if hasattr(att, "m_k"):
         dst.m_k, dst.m_v = _p(att.m_k.detach()), _p(att.m_v.detach())
 
 
-def _ffn(dst, pwff):
-    _lin(dst.fc1, pwff.fc1); _lin(dst.fc2, pwff.fc2); _norm(dst.ln, pwff.layer_norm)
+def _ffn(dst, pwff, planes=None, mode=0):
+    _lin(dst.fc1, pwff.fc1, planes, mode); _lin(dst.fc2, pwff.fc2, planes, mode); _norm(dst.ln, pwff.layer_norm)
 
 
 class CaptionEngine:
@@ -79,6 +112,9 @@ class CaptionEngine:
     # (scaled residual, 3 products, 22 bits per operand) -- faster, fp32 in and out, but NOT bit-identical to "f32"
     # (DESIGN.md has the measured token-id agreement of each mode).
     PRECISIONS = {"f32": 0, "bf16": 1, "bf16x3": 2, "bf16x6": 3, "f16x3": 4}
+    # split-precision modes: cut every GEMM weight into its planes once (and again when it changes) instead of in every
+    # workgroup of every launch -- same bits, W then bypasses conversion and LDS (OVC_PRECUT_WEIGHTS=0: A/B switch)
+    precut_weights = os.environ.get("OVC_PRECUT_WEIGHTS", "1") != "0"
     precision = os.environ.get("OVC_PRECISION", "f32")
 
     def __init__(self, model, tune_concurrency=None, precision=None):
@@ -92,6 +128,8 @@ class CaptionEngine:
             self.tune_concurrency = int(tune_concurrency)
         self._keep = []          # tensors created here whose storage the pointer table references
         self._fc_g = None
+        # split-precision modes: the GEMM weights pre-cut into 16-bit planes (read straight from memory by the kernels)
+        self._planes = _WeightPlanes(self.lib) if self.precision != "f32" and self.precut_weights else None
         self.desc = self._describe(model)
         self._workspaces = {}    # one scratch buffer per HIP stream: concurrent batches never share state
         self._tuned = set()
@@ -122,7 +160,9 @@ class CaptionEngine:
         d.ln_eps = enc.layer_norm.eps
         if len(enc.layers) > native.OVC_MAX_LAYERS or len(dec.layers) > native.OVC_MAX_LAYERS:
             raise native.OvcError("at most {} layers are supported".format(native.OVC_MAX_LAYERS))
-        _lin(d.proj, model.vision_embedding.proj)
+        mode = self.PRECISIONS[self.precision]
+        pl = self._planes
+        _lin(d.proj, model.vision_embedding.proj, pl, 3 if mode == 4 else mode)   # f16x3: the features go through bf16 planes
         _norm(d.enc_ln, enc.layer_norm)
         if d.enc_kind == native.ENC_GEOMETRIC:
             d.trig, d.d_g = int(bool(enc.trignometric_embedding)), enc.d_g
@@ -134,18 +174,20 @@ class CaptionEngine:
             self._keep += [w, b]
             d.fc_g_w, d.fc_g_b = _p(w), _p(b)
         for i, layer in enumerate(enc.layers):
-            _mha(d.enc[i].att, layer.mhatt, self._keep)
-            _ffn(d.enc[i].ffn, layer.pwff)
+            _mha(d.enc[i].att, layer.mhatt, self._keep, pl, mode)
+            _ffn(d.enc[i].ffn, layer.pwff, pl, mode)
         for i, layer in enumerate(dec.layers):
-            _mha(d.dec[i].self_att, layer.self_attn, self._keep)
-            _mha(d.dec[i].cross_att, layer.enc_attn, self._keep)
-            _ffn(d.dec[i].ffn, layer.pwff)
+            _mha(d.dec[i].self_att, layer.self_attn, self._keep, pl, mode)
+            _mha(d.dec[i].cross_att, layer.enc_attn, self._keep, pl, mode)
+            _ffn(d.dec[i].ffn, layer.pwff, pl, mode)
             if d.dec_kind == native.DEC_MESHED:
                 for j, fc in enumerate(layer.fc_alphas):
-                    _lin(d.dec[i].alpha[j], fc)
+                    _lin(d.dec[i].alpha[j], fc, pl, mode)
         d.word_emb = _p(dec.word_emb.components.weight.detach())
         d.pos_emb = _p(dec.pos_emb.weight.detach())
         d.fc = _p(dec.fc.weight.detach())
+        if pl is not None and dec.fc.weight.shape[1] % 16 == 0:
+            d.fc_planes = pl.add(dec.fc.weight, mode)
         d.tune_objective = max(1, min(8, int(self.tune_concurrency)))
         d.precision = self.PRECISIONS[self.precision]
         if self.precision == "f16x3":
@@ -163,6 +205,14 @@ class CaptionEngine:
             enc = self.model.encoder
             torch.cat([fc.weight.detach() for fc in enc.fc_gs], dim=0, out=self._fc_g[0])
             torch.cat([fc.bias.detach() for fc in enc.fc_gs], dim=0, out=self._fc_g[1])
+        if self._planes is not None:
+            self._planes.refresh()
+
+    def recut_weights(self):
+        """Split-precision modes: rebuild every weight's pre-cut planes (only needed after modifying weights in a way that
+        does not move their version counter, e.g. through ``.data``)."""
+        if self._planes is not None:
+            self._planes.refresh(force=True)
 
     # -- GEMM tiling selection ------------------------------------------------------------------
     def gemm_shapes(self, B, N, k):
@@ -206,7 +256,9 @@ class CaptionEngine:
         todo = [sh for sh in shapes if self.lib.ovc_gemm_tuned_get(*sh, 1) < 0]
         if todo:
             # operands + output (K-split shapes: one partial output per slice)
-            need = max(4 * (m * kk + sn * ns * kk + m * sn * ns * ks) + 256 for m, sn, ns, kk, _, ks in todo)
+            # (+ room for pre-cut weight planes in the split-precision classes: the tuner then ranks the instances the engine runs)
+            need = max(4 * (m * kk + sn * ns * kk + m * sn * ns * ks) + 256 +
+                       (ns * self.lib.ovc_split_weight_bytes(sn, kk, kc - 100) if kc > 100 else 0) for m, sn, ns, kk, kc, ks in todo)
             scratch = torch.empty(need // 4 + 16, dtype=torch.float32, device=self.device).normal_()
             for sh in todo:
                 check(self.lib.ovc_gemm_tune(*sh, scratch.data_ptr(), scratch.numel() * 4, native.stream_handle()),

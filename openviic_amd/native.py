@@ -12,7 +12,7 @@ OVC_MAX_LAYERS = 8
 OVC_MAX_LEVELS = 4
 OVC_MAX_BEAM = 8
 OVC_PROFILE_CLASSES = 4
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 _ERRORS = {-1: "OVC_EINVAL (bad argument / unsupported shape)", -2: "OVC_EWORKSPACE (workspace too small)",
            -3: "OVC_ELAUNCH (HIP launch failed)"}
@@ -23,7 +23,7 @@ class OvcError(RuntimeError):
 
 
 class Lin(ctypes.Structure):
-    _fields_ = [("w", c_void_p), ("b", c_void_p)]
+    _fields_ = [("w", c_void_p), ("b", c_void_p), ("planes", c_void_p)]
 
 
 class Norm(ctypes.Structure):
@@ -56,7 +56,7 @@ class Model(ctypes.Structure):
         ("bos_idx", c_int32), ("eos_idx", c_int32), ("ln_eps", c_float),
         ("proj", Lin), ("enc_ln", Norm), ("fc_g_w", c_void_p), ("fc_g_b", c_void_p),
         ("enc", EncLayer * OVC_MAX_LAYERS), ("dec", DecLayer * OVC_MAX_LAYERS),
-        ("word_emb", c_void_p), ("pos_emb", c_void_p), ("fc", c_void_p), ("tune_objective", c_int32), ("precision", c_int32),
+        ("word_emb", c_void_p), ("pos_emb", c_void_p), ("fc", c_void_p), ("fc_planes", c_void_p), ("tune_objective", c_int32), ("precision", c_int32),
     ]
 
 
@@ -100,6 +100,10 @@ SIGNATURES = {
     "ovc_graph_cache_size": (c_int, []),
     "ovc_debug_force_gemm_tiling": (c_int, [c_int]),
     "ovc_debug_linear_tiling": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "ovc_split_weight_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "ovc_split_weight": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "ovc_debug_linear_planes": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                                        c_void_p]),
     "ovc_debug_repeat_linear": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "ovc_beam_search_graph": (c_int, [POINTER(Model), c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_size_t,
                                       c_void_p, c_void_p, c_void_p]),

@@ -396,7 +396,20 @@ def test_split_precision_modes_are_opt_in_deterministic_and_measured(mode, produ
         w = model.encoder.layers[0].pwff.fc1.weight
         keep = w.detach().clone()
         try:
+            # the pre-cut weight planes follow an in-place update (version counter) and agree with cutting in the kernel
             with torch.no_grad():
+                w.mul_(1.25)
+                after = engine.beam_search(x, None, 48, 5)
+                fresh = CaptionEngine(model, precision="f16x3").beam_search(x, None, 48, 5)
+                uncut = CaptionEngine(model, precision="f16x3")
+                uncut._planes = None
+                uncut.desc = uncut._describe(model)
+                in_kernel = uncut.beam_search(x, None, 48, 5)
+            assert torch.equal(after[0], fresh[0]) and torch.equal(after[1], fresh[1])
+            assert torch.equal(after[0], in_kernel[0]) and torch.equal(after[1], in_kernel[1])
+            assert not torch.equal(after[1], lp)
+            with torch.no_grad():
+                w.copy_(keep)
                 w[0, 0] = 1.0e5
             with pytest.raises(native.OvcError):
                 CaptionEngine(model, precision="f16x3")

@@ -453,6 +453,38 @@ def test_every_tiling_of_a_k_order_class_gives_the_same_bits(M, N, K):
         assert err[104] < err[102] / 2, err                      # two fp16 planes: 22 bits from the same 3 products
 
 
+@pytest.mark.parametrize("M,N,K,ksplit", [(130, 200, 96, 1), (65, 33, 48, 1), (1280, 512, 512, 2), (31, 10201, 64, 1), (640, 40, 2048, 4),
+                                          (5, 64, 32, 1), (257, 1536, 128, 1)])
+def test_pre_cut_weight_planes_give_the_bits_of_cutting_in_the_kernel(M, N, K, ksplit):
+    """Split-precision classes: ovc_split_weight stores W as 16-bit planes in MFMA-operand order, and the GEMM instances that
+    read them straight from memory must reproduce, bit for bit, the instances that cut W themselves through LDS -- for every
+    tiling, with N tails (blocks past the last 32 rows of W), K not a multiple of the K tile (falls back) and K slices."""
+    from openviic_amd import native
+    lib = native.load()
+    lib.ovc_profile_kernel_name.restype = __import__("ctypes").c_char_p
+    g = torch.Generator().manual_seed(M * 3 + N + K)
+    x, w, b = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) / math.sqrt(K), torch.randn(N, generator=g)
+    xd, wd, bd = (t.to(DEV) for t in (x, w, b))
+    assert lib.ovc_split_weight_bytes(N, K + 4, 4) == 0 and lib.ovc_split_weight_bytes(N, K, 5) == 0      # K % 16, unknown mode
+    checked = 0
+    for mode in (1, 2, 3, 4):
+        planes = torch.empty(lib.ovc_split_weight_bytes(N, K, mode), dtype=torch.uint8, device=DEV)
+        assert planes.numel() == ((N + 31) // 32) * (K // 16) * (2 if mode == 4 else mode) * 1024
+        assert lib.ovc_split_weight(wd.data_ptr(), N, K, mode, planes.data_ptr(), native.stream_handle()) == 0
+        for t, name, chains in _tilings(lib):
+            if chains != 100 + mode:
+                continue
+            rc, want = _linear_by_tiling(lib, native, xd, wd, bd, t, ksplit)
+            if rc != 0:           # a slice must be a whole number of this tiling's K tiles
+                continue
+            got = torch.empty_like(want)
+            assert lib.ovc_debug_linear_planes(xd.data_ptr(), K, wd.data_ptr(), planes.data_ptr(), bd.data_ptr(), got.data_ptr(),
+                                               M, N, t, ksplit, 1, native.stream_handle()) == 0, name
+            assert torch.equal(got, want), name
+            checked += 1
+    assert checked >= 12
+
+
 @pytest.mark.parametrize("ksplit", [2, 4])
 def test_k_slices_are_bit_identical_across_tilings_and_sum_to_the_product(ksplit):
     """K-split products (engine: the decode-step projections back to d_model): slice s is the product over

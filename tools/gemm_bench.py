@@ -50,6 +50,21 @@ def time_tiling(lib, x, w, b, y, t, ksplit, iters=40):
     return start.elapsed_time(stop) / iters * 1e3
 
 
+def time_planes(lib, x, w, planes, b, y, t, ksplit, iters=40):
+    M, K = x.shape
+    N = w.shape[0]
+    args = (x.data_ptr(), K, w.data_ptr(), planes.data_ptr(), b.data_ptr(), y.data_ptr(), M, N, t, ksplit)
+    if lib.ovc_debug_linear_planes(*args, 5, native.stream_handle()) != 0:
+        return None
+    torch.cuda.synchronize()
+    start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    start.record()
+    lib.ovc_debug_linear_planes(*args, iters, native.stream_handle())
+    stop.record()
+    torch.cuda.synchronize()
+    return start.elapsed_time(stop) / iters * 1e3
+
+
 def main():
     which = sys.argv[1] if len(sys.argv) > 1 else "all"
     split = "split" in sys.argv[2:]
@@ -99,6 +114,24 @@ def main():
                     want = exact + b.double() if ksplit <= 1 else exact
                     err = (y[:max(ksplit, 1)].double().sum(0) - want).abs().max().item() / scale
             cells.sort()
+            if cls > 100:       # the same tilings on pre-cut weights (ovc_split_weight): bit-identical, W bypasses LDS
+                mode = cls - 100
+                planes = torch.empty(lib.ovc_split_weight_bytes(N, K, mode), dtype=torch.uint8, device="cuda")
+                assert lib.ovc_split_weight(w.data_ptr(), N, K, mode, planes.data_ptr(), native.stream_handle()) == 0
+                direct, same = [], True
+                for t, label, c in tl:
+                    if c != cls:
+                        continue
+                    y.zero_()
+                    us = time_tiling(lib, x, w, b, y, t, ksplit)
+                    ref_y = y.clone()
+                    us2 = time_planes(lib, x, w, planes, b, y, t, ksplit)
+                    if us is None or us2 is None:
+                        continue
+                    same = same and torch.equal(ref_y, y)
+                    direct.append((us2, label))
+                direct.sort()
+                print("      planes:  bit-identical %s | %s" % (same, "  ".join("%s: %.1f (%.0f TF-eq)" % (l, u, flops / u / 1e6) for u, l in direct)), flush=True)
             print("    class %3d: max |err| / mean |y| = %.2e | %s" % (
                 cls, err, "  ".join("%s: %.1f (%.0f TF-eq)" % (l, u, flops / u / 1e6) for u, l in cells)), flush=True)
 
