@@ -94,6 +94,88 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return base + (bid >> 3);
 }
 
+// Which output tile a workgroup owns.  Grouped order inside each XCD's contiguous chunk: super-rows of `group_m` M tiles are
+// swept over all N tiles, M fastest inside the group (the group's A tiles stay in that XCD's L2 for the whole sweep and each
+// weight tile is fetched once per super-row; group_m == tiles_m when all of A fits in L2 anyway) -- or, xcd_pm > 0, a 2-D
+// split of the tile grid over the 8 XCDs (xcd_pm x 8/xcd_pm sub-rectangles, M fastest inside): XCD L2s are private, so with a
+// split along N only every XCD pulls all of A from the Infinity Cache (8 x 2.6 MB for the 1280-row decode products against
+// 3.6 MB of operands); the host picks the split with the least total operand traffic (tile_order).  Needs
+// tiles_m % xcd_pm == 0 and tiles_n_all % (8 / xcd_pm) == 0.
+__device__ __forceinline__ void tile_coords(int tiles_m, int group_m, int xcd_pm, int& tile_m, int& tile_n_all) {
+    const int nwg = gridDim.x;
+    const int tile = xcd_remap(blockIdx.x, nwg);
+    const int tiles_n_all = nwg / tiles_m;
+    if (xcd_pm > 0) {
+        const int per_chunk = nwg >> 3, chunk = tile / per_chunk, j = tile - chunk * per_chunk;
+        const int sub_m = tiles_m / xcd_pm, cm = chunk % xcd_pm, cn = chunk / xcd_pm;
+        const int sub_n = tiles_n_all / (8 / xcd_pm);
+        tile_m = cm * sub_m + j % sub_m;
+        tile_n_all = cn * sub_n + j / sub_m;
+    } else {
+        const int group_size = group_m * tiles_n_all;
+        const int group = tile / group_size;
+        const int first_m = group * group_m;
+        const int gm = min(group_m, tiles_m - first_m);
+        const int in_group = tile - group * group_size;
+        tile_n_all = in_group / gm;
+        tile_m = first_m + (in_group - tile_n_all * gm);
+    }
+}
+
+// Epilogue of a wave's TM x TN accumulator tiles: + bias, activation, + residual, store (or, K-split, the raw partial product
+// of slice blockIdx.y).  D layout of a 32x32 tile: col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).  Branch-free on buffer
+// descriptors: one per-lane byte offset (first row of the lane's 16, its column) and a scalar row offset per accumulator
+// register; rows past M fall outside the descriptor and are dropped by the hardware, columns past seg_n get an
+// out-of-range offset.  (m0, n0) = first row / column of the wave's tiles.
+template <int TM, int TN>
+__device__ __forceinline__ void store_wave_tiles(const GemmArgs& p, int seg, const f32x16 (&acc)[TM][TN], int m0, int n0, int lane) {
+    const float* __restrict__ bias = p.seg[seg].bias;
+    float* __restrict__ C = p.seg[seg].C + (size_t)blockIdx.y * p.part_stride;
+    const int half = lane >> 5;
+    const bool has_res = p.R != nullptr;                          // uniform
+    const __amdgpu_buffer_rsrc_t rsrc_c = __builtin_amdgcn_make_buffer_rsrc(C, 0, p.M * p.ldc * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(has_res ? p.R : p.A1), 0,
+                                                                             has_res && p.res_mod == 0 ? p.M * p.ldr * 4 : 0, 0x00020000);
+    constexpr int kOutOfRange = 0x7ffffff0;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + j * 32 + (lane & 31);
+        const bool n_ok = n < p.seg_n;
+        const float bv = bias ? bias[min(n, p.seg_n - 1)] : 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int mbase = m0 + i * 32 + 4 * half;
+            float out[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float v = acc[i][j][r] + bv;
+                out[r] = p.act == 1 ? fmaxf(v, 0.f) : v;
+            }
+            if (has_res) {
+                float res[16];
+                if (p.res_mod == 0) {
+                    const int voff_r = n_ok ? (mbase * p.ldr + n) * 4 : kOutOfRange;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        res[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc_r, voff_r, ((r & 3) + 8 * (r >> 2)) * p.ldr * 4, 0));
+                } else {                                           // residual broadcast over stacked row blocks
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int mc = min(mbase + (r & 3) + 8 * (r >> 2), p.M - 1) % p.res_mod;
+                        res[r] = p.R[(size_t)mc * p.ldr + min(n, p.seg_n - 1)];
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) out[r] += res[r];
+            }
+            const int voff_c = n_ok ? (mbase * p.ldc + n) * 4 : kOutOfRange;
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, out[r]), rsrc_c, voff_c, ((r & 3) + 8 * (r >> 2)) * p.ldc * 4, 0);
+        }
+    }
+}
+
 #include "gemm_split.h"   // gemm_split_mfma: the opt-in split-precision classes (bf16 planes on the 16-bit matrix path)
 
 // Registers are capped where residency matters: the M = 1280 decode products come as 1280 workgroups of 32x64 tiles,
@@ -115,33 +197,8 @@ __global__ __launch_bounds__(256, (min_waves_per_simd<BM, BN, BK, NC>())) void g
     const int wk = wave / (WM * WN);
     const int wm = (wave / WN) % WM, wn = wave % WN;
 
-    const int nwg = gridDim.x;
-    // Grouped order inside each XCD's contiguous chunk: super-rows of `group_m` M tiles are swept over
-    // all N tiles, M fastest inside the group.  The group's A tiles stay in that XCD's L2 for the whole
-    // sweep and each weight tile is fetched once per super-row; group_m == tiles_m (plain M-fastest) is
-    // used when all of A fits in L2 anyway.
-    const int tile = xcd_remap(blockIdx.x, nwg);
-    const int tiles_n_all = nwg / tiles_m;
     int tile_m, tile_n_all;
-    if (xcd_pm > 0) {
-        // 2-D split of the tile grid over the 8 XCDs (xcd_pm x 8/xcd_pm sub-rectangles, M fastest inside): XCD L2s
-        // are private, so with a split along N only every XCD pulls all of A from the Infinity Cache (8 x 2.6 MB
-        // for the 1280-row decode products against 3.6 MB of operands); the host picks the split with the least
-        // total operand traffic.  Needs tiles_m % xcd_pm == 0 and tiles_n_all % (8 / xcd_pm) == 0.
-        const int per_chunk = nwg >> 3, chunk = tile / per_chunk, j = tile - chunk * per_chunk;
-        const int sub_m = tiles_m / xcd_pm, cm = chunk % xcd_pm, cn = chunk / xcd_pm;
-        const int sub_n = tiles_n_all / (8 / xcd_pm);
-        tile_m = cm * sub_m + j % sub_m;
-        tile_n_all = cn * sub_n + j / sub_m;
-    } else {
-        const int group_size = group_m * tiles_n_all;
-        const int group = tile / group_size;
-        const int first_m = group * group_m;
-        const int gm = min(group_m, tiles_m - first_m);
-        const int in_group = tile - group * group_size;
-        tile_n_all = in_group / gm;
-        tile_m = first_m + (in_group - tile_n_all * gm);
-    }
+    tile_coords(tiles_m, group_m, xcd_pm, tile_m, tile_n_all);
     const int seg = tile_n_all / tiles_n_per_seg;
     const int tile_n = tile_n_all - seg * tiles_n_per_seg;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
@@ -329,55 +386,7 @@ __global__ __launch_bounds__(256, (min_waves_per_simd<BM, BN, BK, NC>())) void g
         }
     }
 
-    // Epilogue.  D layout of the 32x32 tile: col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
-    // Branch-free epilogue on buffer descriptors: one per-lane byte offset (first row of the lane's 16, its
-    // column) and a scalar row offset per accumulator register; rows past M fall outside the descriptor and
-    // are dropped by the hardware, columns past seg_n get an out-of-range offset.
-    const float* __restrict__ bias = p.seg[seg].bias;
-    float* __restrict__ C = p.seg[seg].C + (size_t)blockIdx.y * p.part_stride;
-    const int half = lane >> 5;
-    const bool has_res = p.R != nullptr;                          // uniform
-    const __amdgpu_buffer_rsrc_t rsrc_c = __builtin_amdgcn_make_buffer_rsrc(C, 0, p.M * p.ldc * 4, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsrc_r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(has_res ? p.R : p.A1), 0,
-                                                                             has_res && p.res_mod == 0 ? p.M * p.ldr * 4 : 0, 0x00020000);
-    constexpr int kOutOfRange = 0x7ffffff0;
-#pragma unroll
-    for (int j = 0; j < Cfg::TN; ++j) {
-        const int n = n0 + wn * Cfg::kWaveN + j * 32 + (lane & 31);
-        const bool n_ok = n < p.seg_n;
-        const float bv = bias ? bias[min(n, p.seg_n - 1)] : 0.f;
-#pragma unroll
-        for (int i = 0; i < Cfg::TM; ++i) {
-            const int mbase = m0 + wm * Cfg::kWaveM + i * 32 + 4 * half;
-            float out[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float v = acc[0][i][j][r] + bv;
-                out[r] = p.act == 1 ? fmaxf(v, 0.f) : v;
-            }
-            if (has_res) {
-                float res[16];
-                if (p.res_mod == 0) {
-                    const int voff_r = n_ok ? (mbase * p.ldr + n) * 4 : kOutOfRange;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        res[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc_r, voff_r, ((r & 3) + 8 * (r >> 2)) * p.ldr * 4, 0));
-                } else {                                           // residual broadcast over stacked row blocks
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int mc = min(mbase + (r & 3) + 8 * (r >> 2), p.M - 1) % p.res_mod;
-                        res[r] = p.R[(size_t)mc * p.ldr + min(n, p.seg_n - 1)];
-                    }
-                }
-#pragma unroll
-                for (int r = 0; r < 16; ++r) out[r] += res[r];
-            }
-            const int voff_c = n_ok ? (mbase * p.ldc + n) * 4 : kOutOfRange;
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, out[r]), rsrc_c, voff_c, ((r & 3) + 8 * (r >> 2)) * p.ldc * 4, 0);
-        }
-    }
+    store_wave_tiles<Cfg::TM, Cfg::TN>(p, seg, acc[0], m0 + wm * Cfg::kWaveM, n0 + wn * Cfg::kWaveN, lane);
 }
 
 // tile order shared by both kernels: super-rows of M tiles when the A panel exceeds an L2, else the 2-D XCD split with

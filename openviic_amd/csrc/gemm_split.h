@@ -118,26 +118,8 @@ __global__ __launch_bounds__(256) void gemm_split_mfma(GemmArgs p, int tiles_m, 
     const int wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
 
-    // tile order: as gemm_f32_mfma (contiguous chunk per XCD; super-rows or a 2-D split chosen by the host)
-    const int nwg = gridDim.x;
-    const int tile = xcd_remap(blockIdx.x, nwg);
-    const int tiles_n_all = nwg / tiles_m;
     int tile_m, tile_n_all;
-    if (xcd_pm > 0) {
-        const int per_chunk = nwg >> 3, chunk = tile / per_chunk, j = tile - chunk * per_chunk;
-        const int sub_m = tiles_m / xcd_pm, cm = chunk % xcd_pm, cn = chunk / xcd_pm;
-        const int sub_n = tiles_n_all / (8 / xcd_pm);
-        tile_m = cm * sub_m + j % sub_m;
-        tile_n_all = cn * sub_n + j / sub_m;
-    } else {
-        const int group_size = group_m * tiles_n_all;
-        const int group = tile / group_size;
-        const int first_m = group * group_m;
-        const int gm = min(group_m, tiles_m - first_m);
-        const int in_group = tile - group * group_size;
-        tile_n_all = in_group / gm;
-        tile_m = first_m + (in_group - tile_n_all * gm);
-    }
+    tile_coords(tiles_m, group_m, xcd_pm, tile_m, tile_n_all);     // as gemm_f32_mfma
     const int seg = tile_n_all / tiles_n_per_seg;
     const int tile_n = tile_n_all - seg * tiles_n_per_seg;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
@@ -324,50 +306,5 @@ __global__ __launch_bounds__(256) void gemm_split_mfma(GemmArgs p, int tiles_m, 
                         acc[c - 1][i][j][r] = fmaf(acc[c][i][j][r], 1.f / kHalfResidualScale, acc[c - 1][i][j][r]);
     }
 
-    // Epilogue: as gemm_f32_mfma (D layout of a 32x32 tile: col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)).
-    const float* __restrict__ bias = p.seg[seg].bias;
-    float* __restrict__ C = p.seg[seg].C + (size_t)blockIdx.y * p.part_stride;
-    const int half = lane >> 5;
-    const bool has_res = p.R != nullptr;
-    const __amdgpu_buffer_rsrc_t rsrc_c = __builtin_amdgcn_make_buffer_rsrc(C, 0, p.M * p.ldc * 4, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsrc_r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(has_res ? p.R : p.A1), 0,
-                                                                             has_res && p.res_mod == 0 ? p.M * p.ldr * 4 : 0, 0x00020000);
-    constexpr int kOutOfRange = 0x7ffffff0;
-#pragma unroll
-    for (int j = 0; j < Cfg::TN; ++j) {
-        const int n = n0 + wn * Cfg::kWaveN + j * 32 + (lane & 31);
-        const bool n_ok = n < p.seg_n;
-        const float bv = bias ? bias[min(n, p.seg_n - 1)] : 0.f;
-#pragma unroll
-        for (int i = 0; i < Cfg::TM; ++i) {
-            const int mbase = m0 + wm * Cfg::kWaveM + i * 32 + 4 * half;
-            float out[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float v = acc[0][i][j][r] + bv;
-                out[r] = p.act == 1 ? fmaxf(v, 0.f) : v;
-            }
-            if (has_res) {
-                float res[16];
-                if (p.res_mod == 0) {
-                    const int voff_r = n_ok ? (mbase * p.ldr + n) * 4 : kOutOfRange;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        res[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc_r, voff_r, ((r & 3) + 8 * (r >> 2)) * p.ldr * 4, 0));
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int mc = min(mbase + (r & 3) + 8 * (r >> 2), p.M - 1) % p.res_mod;
-                        res[r] = p.R[(size_t)mc * p.ldr + min(n, p.seg_n - 1)];
-                    }
-                }
-#pragma unroll
-                for (int r = 0; r < 16; ++r) out[r] += res[r];
-            }
-            const int voff_c = n_ok ? (mbase * p.ldc + n) * 4 : kOutOfRange;
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, out[r]), rsrc_c, voff_c, ((r & 3) + 8 * (r >> 2)) * p.ldc * 4, 0);
-        }
-    }
+    store_wave_tiles<Cfg::TM, Cfg::TN>(p, seg, acc[0], m0 + wm * Cfg::kWaveM, n0 + wn * Cfg::kWaveN, lane);
 }
