@@ -2,7 +2,8 @@
 """Headline benchmark: captions/s of beam-5 decoding on synthetic region features.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--config standard_transformer]
-                    [--batch 256] [--beam 5] [--no-cpu-baseline]
+                    [--batch 256] [--beam 5] [--streams 4] [--tune-concurrency C] [--no-cpu-baseline]
+                    [--precision f32] [--also-precision f16x3|none]
 
 One "step" is one pass of the hot path over one batch: ``[B=256, 50, 2048]`` fp32 region features
 already resident in HBM -> encoder -> 20 beam-search steps (beam 5, V=10201) -> token ids
@@ -21,6 +22,12 @@ wall time, so that leg runs on ONE stream, right after a timed single-stream reg
 next to it (``roofline.single_stream``); ``roofline.timed_mode`` relates the same GEMM FLOPs to the headline wall time.
 ``cpu_baseline`` times the CPU oracle (which reproduces the reference's operation sequence): B = 256, one warm-up and
 three timed repeats.
+
+Everything above is fp32 MFMA arithmetic -- the parity mode and the only thing ``value`` ever means.  ``opt_in_precision``
+(one GPU, after all fp32 legs) is a separately reported leg in an opt-in split-precision engine mode (default f16x3:
+GEMMs on two fp16 planes of the fp32 operands, fp32 accumulation) with the fraction of the batch's
+captions that come out identical to the fp32 engine's; ``--precision`` runs the whole bench in such a mode and says so in
+``dtype``.
 """
 import argparse
 import json
