@@ -75,10 +75,10 @@ def parse():
     ap.add_argument("--tune-concurrency", type=int, default=0,
                     help="GEMM tuning objective of the timed region's engine: tilings ranked by the time of this many "
                          "co-running copies (0 = 2 with three or more streams, else 1).  Changes speed only, never a bit.")
-    ap.add_argument("--precision", default="f32", choices=["f32", "bf16", "bf16x3", "bf16x6", "f16x3"],
+    ap.add_argument("--precision", default="f32", choices=["f32", "bf16x6", "f16x3"],
                     help="GEMM arithmetic.  f32 (default) = fp32 MFMA, the parity mode and the only headline.  The others are the "
                          "opt-in split-precision modes (bf16 planes, fp32 accumulate), reported separately: NOT bit-identical to f32.")
-    ap.add_argument("--also-precision", default="f16x3", choices=["none", "bf16", "bf16x3", "bf16x6", "f16x3"],
+    ap.add_argument("--also-precision", default="f16x3", choices=["none", "bf16x6", "f16x3"],
                     help="with --precision f32 on one GPU: an extra, separately reported leg in this opt-in mode "
                          "(same streams, same steps; never part of `value`)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -87,27 +87,60 @@ def parse():
     return ap.parse_args()
 
 
-def profiled_gemm_traffic(variant):
-    """HBM bytes per GEMM launch from the committed PMC passes of this workload (profiles/*_per_kernel_shape.csv,
+PROFILE_VARIANT_TAGS = ("meshed_memory_transformer", "object_relation_transformer", "attention_on_attention")
+PROFILE_PRECISION_TAGS = ("f16x3", "bf16x6", "bf16x3", "bf16")   # tags of committed profiles (round 2 had two more modes)
+# compulsory HBM bytes per batch: features in + ids / log-probs out per caption, cross-K/V written
+# once and read once per decoder layer and step is NOT compulsory (it could stay on chip), weights read once per batch
+WEIGHT_BYTES = {"standard_transformer": 134.0e6, "standard_transformer_using_region": 134.0e6,
+                "object_relation_transformer": 134.0e6}
+
+
+def profiled_gemm_traffic(variant, precision="f32", profiles_dir=None):
+    """HBM bytes moved by the GEMM launches of this workload, from the committed PMC passes (profiles/*_per_kernel_shape.csv,
     produced by tools/profile_round.sh: separate FETCH_SIZE / WRITE_SIZE runs, FETCH_SIZE doubled as the gfx950 guide
-    prescribes), launch-weighted over the GEMM rows.  Not a live measurement: None when the file is absent."""
+    prescribes).  Returns (bytes per GEMM launch, launch-weighted; file name; counter bytes per batch over ALL kernels of the
+    file) or (None, None, None).  Not a live measurement.
+
+    The file is chosen by workload AND arithmetic: ``r<NN><letter>[_<variant>][_<precision>]_per_kernel_shape.csv`` whose
+    variant tag equals the benchmarked architecture (none = standard transformer) and whose precision tag equals the mode
+    (none = fp32), and whose GEMM rows carry the kernel family of that mode; the newest such file wins."""
     import csv
     import glob
-    suffix = "" if variant.startswith("standard") else "_" + variant
-    files = sorted(f for f in glob.glob(os.path.join(REPO, "profiles", "r[0-9][0-9]*%s_per_kernel_shape.csv" % suffix))
-                   if suffix or not any(v in os.path.basename(f) for v in ("meshed", "object_relation", "attention_on")))
-    if not files:
-        return None, None
-    launches = total = 0.0
-    for row in csv.DictReader(open(files[-1])):
-        if not row["kernel"].startswith("gemm_f32_mfma") or not row["hbm_read_MB_per_launch"]:
+    import re
+    family = "gemm_f32_mfma" if precision == "f32" else "gemm_split_mfma"
+    want_variant = "" if variant.startswith("standard") else variant
+    want_precision = "" if precision == "f32" else precision
+    chosen = None
+    for path in sorted(glob.glob(os.path.join(profiles_dir or os.path.join(REPO, "profiles"), "r[0-9][0-9]*_per_kernel_shape.csv"))):
+        m = re.match(r"r\d\d[a-z]?_?(.*?)_?per_kernel_shape\.csv$", os.path.basename(path))
+        if not m:
             continue
-        n = float(row["launches_per_batch"])
-        launches += n
-        total += n * (float(row["hbm_read_MB_per_launch"]) + float(row["hbm_write_MB_per_launch"] or 0.0)) * 1048576.0
-    if not launches:
-        return None, None
-    return round(total / launches, 0), os.path.basename(files[-1])
+        tag = m.group(1)
+        file_variant = next((v for v in PROFILE_VARIANT_TAGS if v in tag), "")
+        rest = tag.replace(file_variant, "")
+        file_precision = next((p for p in PROFILE_PRECISION_TAGS if p in rest), "")
+        if file_variant != want_variant or file_precision != want_precision or "4streams" in rest:
+            continue
+        launches = total = everything = 0.0
+        for row in csv.DictReader(open(path)):
+            if not row["hbm_read_MB_per_launch"]:
+                continue
+            n = float(row["launches_per_batch"])
+            moved = n * (float(row["hbm_read_MB_per_launch"]) + float(row["hbm_write_MB_per_launch"] or 0.0)) * 1048576.0
+            everything += moved
+            if row["kernel"].startswith(family):
+                launches += n
+                total += moved
+        if launches:
+            chosen = (round(total / launches, 0), os.path.basename(path), round(everything, 0))
+    return chosen or (None, None, None)
+
+
+def algorithmic_bytes(variant, B):
+    """Compulsory HBM bytes of one batch: per caption 409 600 B of features in, 614 400 B of
+    cross-attention K/V written once, 240 B of ids and log-probs out; the weights once per batch."""
+    weights = WEIGHT_BYTES.get(variant)
+    return None if weights is None else float(B * (409600 + 614400 + 240) + weights)
 
 
 def usable_cores():
@@ -168,8 +201,17 @@ def cpu_baseline(cfg, sd, variant, beam, sample, repeats):
         print("[bench] cpu baseline %s: %.2f s" % ("warm-up" if rep == 0 else "repeat %d" % rep, dt), file=sys.stderr, flush=True)
         if rep:
             times.append(dt)
+    # BASELINE config 1 (the reference's own CPU-runnable case): greedy decode, B = 4, same weights, 1 warm-up + 5 timed calls
+    greedy = []
+    for rep in range(6):
+        t0 = time.perf_counter()
+        oracle.beam_search(feats[:4], 1, boxes=None if boxes is None else boxes[:4])
+        if rep:
+            greedy.append(time.perf_counter() - t0)
     return {"value": round(sample / statistics.median(times), 3), "unit": "captions/s", "cores": cores,
             "kind": "port", "cpu": cpu,
+            "config1_greedy_b4": {"value": round(4 / statistics.median(greedy), 2), "unit": "captions/s",
+                                  "sample": "B=4, beam 1 (greedy), 1 warm-up + 5 timed calls, median %.3f s" % statistics.median(greedy)},
             "sample": "B=%d images per call, beam %d, same weights/inputs as the GPU run, 1 warm-up + %d timed calls "
                       "(median; min %.2f s, max %.2f s), torch %s CPU fp32, %d threads"
                       % (sample, beam, repeats, min(times), max(times), torch.__version__, cores)}
@@ -317,13 +359,13 @@ def main():
               % (captions_per_s, 1e3 * elapsed / args.steps, all_gemm, tot_n, 1e3 * tot_ms / max(tot_n, 1)),
               file=sys.stderr, flush=True)
         gflop = GFLOP_PER_CAPTION.get(variant)
-        traffic, traffic_source = profiled_gemm_traffic(variant) if B == 256 and k == 5 else (None, None)
-        split_products = {"f32": 0, "bf16": 1, "bf16x3": 3, "bf16x6": 6, "f16x3": 3}[args.precision]
+        traffic, traffic_source, counter_bytes = (profiled_gemm_traffic(variant, args.precision) if B == 256 and k == 5
+                                                  else (None, None, None))
+        split_products = {"f32": 0, "bf16x6": 6, "f16x3": 3}[args.precision]
         if split_products:      # opt-in mode: the peak is the bf16 dense MFMA rate shared by the plane products of one fp32 product
             PEAK = round(PEAK_F32_MFMA_TFLOPS * 16 / split_products, 1)
             kernel_label = ("gemm_split_mfma<BM,BN,WM,WN,BK,MODE> (v_mfma_f32_32x32x16_bf16 / _f16, %d plane products per product; "
                             "achieved / peak in fp32-product-equivalent TFLOP/s), all tilings" % split_products)
-            traffic = None
         else:
             PEAK = PEAK_F32_MFMA_TFLOPS
             kernel_label = "gemm_f32_mfma<BM,BN,WM,WN,WK,BK> (v_mfma_f32_32x32x2_f32), all tilings"
@@ -332,6 +374,12 @@ def main():
                     "frac": round(all_gemm / PEAK, 4), "traffic": traffic,
                     "traffic_source": ("HBM bytes per launch (read + write), rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes: profiles/%s"
                                        % traffic_source) if traffic else None,
+                    # waste indicator: counter bytes of ALL kernels of one batch over the compulsory bytes of one batch
+                    # (features in, cross-K/V written once, ids / log-probs out, weights once: SURVEY.md section 8d)
+                    "traffic_per_batch": counter_bytes,
+                    "algorithmic_bytes_per_batch": algorithmic_bytes(variant, B),
+                    "traffic_ratio": (round(counter_bytes / algorithmic_bytes(variant, B), 1)
+                                      if counter_bytes and algorithmic_bytes(variant, B) else None),
                     "launches_per_step": tot_n, "avg_launch_us": round(1e3 * tot_ms / max(tot_n, 1), 2),
                     "flops_per_launch": round(tot_fl / max(tot_n, 1), 0), "kernel_ms_per_step": round(tot_ms, 3),
                     "timing": "hipExtLaunchKernelGGL start/stop events (dispatch begin/end timestamps) on the launch "

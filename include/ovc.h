@@ -12,6 +12,13 @@
  * the GEMM tuning table, the hipGraph cache and the profiling counters, each behind its own
  * mutex: the library may be driven from several host threads (one stream per thread; the debug
  * hook ovc_debug_force_gemm_tiling is the one exception and says so).
+ *
+ * ONE DEVICE PER PROCESS.  That state belongs to a device (kernel attributes raised once, the
+ * graph-capture stream, captured graphs, tiling timings), and the deployment model is one process
+ * per GPU (torch.distributed / RCCL).  The first launching call binds the library to the device
+ * that is current on the calling thread; every later call made while another device is current
+ * returns OVC_EDEVICE instead of capturing or launching on the wrong device.  ovc_bound_device()
+ * reports the binding (-1 = none yet).
  */
 #ifndef OVC_H_
 #define OVC_H_
@@ -29,6 +36,7 @@ typedef void* ovc_stream;              /* a hipStream_t (NULL = the null stream)
 #define OVC_EINVAL       -1            /* bad argument / unsupported shape   */
 #define OVC_EWORKSPACE   -2            /* workspace too small                */
 #define OVC_ELAUNCH      -3            /* hipGetLastError() != hipSuccess    */
+#define OVC_EDEVICE      -4            /* current device != the device the library is bound to (one per process) */
 
 #define OVC_MAX_LAYERS    8
 #define OVC_MAX_LEVELS    4
@@ -38,6 +46,8 @@ typedef void* ovc_stream;              /* a hipStream_t (NULL = the null stream)
 /* library / build identification ------------------------------------------------------ */
 int         ovc_abi_version(void);             /* bumps when a struct layout changes     */
 const char* ovc_build_info(void);              /* "gfx950 fp32-mfma ..."                 */
+int         ovc_bound_device(void);            /* device the process is bound to, -1 = none yet */
+int         ovc_debug_rebind_device(int device);   /* tests only: overwrite the binding (-1 = unbound) */
 
 /* ======================================================================================
  * Operator level (parity-test surface; also what the host-side modules call)
@@ -178,14 +188,15 @@ typedef struct {
                                          -- for hosts that keep several batches in flight on different streams.
                                          Speed only: all tilings of a K-order class give the same bits.            */
     int32_t precision;                /* 0 = fp32 MFMA everywhere: the parity mode and the only one the headline numbers
-                                         use.  1 / 2 / 3 = OPT-IN split precision: every GEMM of the engine cuts its fp32
-                                         operands into that many bf16 planes and contracts them on the 16-bit matrix path
-                                         with fp32 accumulation (1, 3 or 6 plane products: "bf16", "bf16x3", "bf16x6");
-                                         4 = two fp16 planes with a scaled residual, 3 products ("f16x3"; weights must lie
-                                         in fp16's range -- the feature projection takes mode 3, so features need not).  K-order classes 101..104.  fp32 in, fp32 out, attention /
-                                         LayerNorm / selection unchanged; results differ from mode 0 in the low-order
-                                         bits (3, 4), at ~1e-5 (2) or ~1e-2 (1) relative -- see DESIGN.md for the
-                                         measured token-id agreement.                                                  */
+                                         use.  OPT-IN, uncredited split precision (fp32 in, fp32 out; attention / LayerNorm /
+                                         selection unchanged; low-order bits differ from mode 0):
+                                         3 = "bf16x6": every GEMM cuts its fp32 operands into three bf16 planes and contracts
+                                         them on the 16-bit matrix path with fp32 accumulation (6 plane products);
+                                         4 = "f16x3": two fp16 planes with a scaled residual, 3 products.  Weights must lie in
+                                         fp16's range (checked by the host); the feature projection takes mode 3, so features
+                                         need not; any other activation outside +-65504 SATURATES at that value while it is
+                                         cut (never inf / NaN).  K-order classes 103 / 104.  1 and 2 (the one- and two-plane
+                                         bf16 modes of ABI 5) failed the parity bar and no longer exist: OVC_EINVAL.   */
 } ovc_model;
 
 /* Sizes the engine accepts (anything else: ovc_workspace_bytes returns 0, the calls OVC_EINVAL) -- the
@@ -221,7 +232,8 @@ int ovc_beam_search(const ovc_model* m, const float* features, const float* boxe
  * the caller's features / boxes run as plain launches, everything else (encoder layers, every
  * decode step, final ordering: ~740 launches whose arguments depend only on the model, the shapes
  * and the workspace) is captured on the second call for a given (model contents, B, N, k, out_size,
- * workspace) and replayed by hipGraphLaunch afterwards.  Graphs are cached process-wide
+ * workspace) and replayed by hipGraphLaunch afterwards.  Graphs are cached process-wide, for the ONE device the
+ * process is bound to (see the top of this header; the workspace pointer in the key is a device address)
  * (ovc_graph_cache_clear releases them); the workspace must stay allocated while they exist. */
 int ovc_beam_search_graph(const ovc_model* m, const float* features, const float* boxes, int B, int N,
                           int k, int out_size, void* workspace, size_t workspace_bytes,
@@ -248,7 +260,7 @@ const char* ovc_profile_kernel_name(int tiling);   /* "" past the last tiling */
  *   kchains = 4   four interleaved chains summed in chain order (the engine's M = B*beam decode-step products);
  *   ksplit  = s   K cut into s contiguous slices whose raw partial products the consuming LayerNorm sums in
  *                 slice order (engine only; a fixed function of K).
- *   kchains = 101 .. 104   the opt-in split-precision classes (ovc_model::precision = 1 .. 4): one chain of
+ *   kchains = 103, 104     the opt-in split-precision classes (ovc_model::precision = 3, 4): one chain of
  *                 16-deep 16-bit MFMA steps, plane products in a fixed order.
  * All tilings of one class produce bit-identical results, so token ids do not depend on the batch size, on the
  * GPU box or on what a timing run picked (the reference is deterministic on CPU: torch.sort path,
@@ -259,24 +271,23 @@ const char* ovc_profile_kernel_name(int tiling);   /* "" past the last tiling */
  * that shape and class use it, and shapes whose M is within a factor of two of a measured one borrow its entry.
  * scratch: >= 4*(M*K + nseg*seg_n*K + ksplit*M*nseg*seg_n) + 64 bytes of device memory (contents are used as
  * operands); for the split-precision classes, nseg * ovc_split_weight_bytes(seg_n, K, kchains - 100) more bytes make the
- * measurement use pre-cut weight planes (what the engine runs when ovc_lin::planes are set).  SYNCHRONISES the stream -- set-up time only.  Thread-safe. */
-int ovc_gemm_tune(int M, int seg_n, int nseg, int K, int kchains, int ksplit, void* scratch, size_t scratch_bytes,
-                  ovc_stream stream);
+ * measurement use pre-cut weight planes (what the engine runs when ovc_lin::planes are set).
+ * `objective` (1..8) = what is minimised: the time of that many identical products co-running in one launch.  1 ranks
+ * tilings by isolated latency, which favours many small tiles; with several independent batches in flight on different
+ * streams, rank with objective = that number: fewer, larger tiles then win because they spend fewer CU-seconds and less
+ * L2 traffic per FLOP.  Each objective has its own table, named explicitly in every call (ABI 6: there is no process-wide
+ * "current objective" any more, so host threads with different objectives cannot cross their entries); which table an
+ * engine call consults is ovc_model::tune_objective.
+ * SYNCHRONISES the stream -- set-up time only.  Thread-safe. */
+int ovc_gemm_tune(int M, int seg_n, int nseg, int K, int kchains, int ksplit, int objective, void* scratch,
+                  size_t scratch_bytes, ovc_stream stream);
 long ovc_gemm_tune_calls(void);        /* measurements run so far in this process */
 
-/* What ovc_gemm_tune minimises: the time of `copies` identical products co-running in one launch (1..8).
- * 1 (default) ranks tilings by isolated latency, which favours many small tiles; with several independent
- * batches in flight on different streams, rank with copies = that number: fewer, larger tiles then win
- * because they spend fewer CU-seconds and less L2 traffic per FLOP.  Each objective has its own table: the setting
- * selects the table that later ovc_gemm_tune / ovc_gemm_tuned_get / ovc_gemm_tuned_set calls work on; which table an
- * engine call consults is ovc_model::tune_objective. */
-int ovc_gemm_tune_objective(int copies);
-
-/* Read / preset the remembered tiling of (shape, class): lets a host persist tuning results.  get returns the
- * tiling index or -1; near != 0 also accepts the entry of the same product with the closest M within a factor of
+/* Read / preset the remembered tiling of (shape, class, objective): lets a host persist tuning results.  get returns
+ * the tiling index or -1; near != 0 also accepts the entry of the same product with the closest M within a factor of
  * two (what a launch falls back to).  set refuses a tiling of another class. */
-int ovc_gemm_tuned_get(int M, int seg_n, int nseg, int K, int kchains, int ksplit, int near);
-int ovc_gemm_tuned_set(int M, int seg_n, int nseg, int K, int kchains, int ksplit, int tiling);
+int ovc_gemm_tuned_get(int M, int seg_n, int nseg, int K, int kchains, int ksplit, int objective, int near);
+int ovc_gemm_tuned_set(int M, int seg_n, int nseg, int K, int kchains, int ksplit, int objective, int tiling);
 
 /* The distinct GEMMs the engine issues for batch B, N regions, beam k: up to `capacity` records of six int32
  * (M, seg_n, nseg, K, kchains, ksplit) are written to `shapes`; returns the number of distinct shapes (which may
@@ -297,7 +308,7 @@ int ovc_debug_force_gemm_tiling(int tiling);
 int ovc_debug_linear_tiling(const float* x, int K, const float* W, const float* bias, float* y, int M, int N,
                             int tiling, int ksplit, int iters, ovc_stream stream);
 
-/* Split-precision modes: a weight W [N, K] (K a multiple of 16) cut ONCE into the 16-bit planes of `mode` (1..4, as
+/* Split-precision modes: a weight W [N, K] (K a multiple of 16) cut ONCE into the 16-bit planes of `mode` (3 or 4, as
  * ovc_model::precision), stored in MFMA-operand order so that the GEMM's waves read them straight from memory instead of
  * cutting W again in every workgroup.  ovc_split_weight_bytes = size of `planes` (0 = invalid arguments); the planes hold the
  * same bits the kernel would cut, so results do not change.  ovc_debug_linear_planes = ovc_debug_linear_tiling on them. */

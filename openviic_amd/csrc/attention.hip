@@ -341,6 +341,7 @@ extern "C" int ovc_attention(const float* q, const float* k, const float* v, int
                              const float* geometry, const float* mem_k, const float* mem_v, int m,
                              float mem_scale_k, float mem_scale_v, float* out, ovc_stream stream) {
     if (!q || !k || !v || !out || b <= 0 || nq <= 0 || nk <= 0 || h <= 0) return OVC_EINVAL;
+    if (const int rc = ovc_device_guard()) return rc;      // kernel attributes below are raised once per process
     if (dk <= 0 || dv <= 0 || (dk & 3) || (dv & 3) || dk > 64 || dv > 64) return OVC_EINVAL;
     if (m < 0 || (m > 0 && (!mem_k || !mem_v)) || nk + m > 128) return OVC_EINVAL;
     if (!ovc_aligned16(q) || !ovc_aligned16(k) || !ovc_aligned16(v)) return OVC_EINVAL;

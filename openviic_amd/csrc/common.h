@@ -16,6 +16,10 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 static inline hipStream_t ovc_hip_stream(ovc_stream s) { return reinterpret_cast<hipStream_t>(s); }
 
+// OVC_OK when the calling thread's current device is the one the library is bound to (binding it on first use),
+// OVC_EDEVICE otherwise (include/ovc.h: one device per process).  Defined in gemm.hip.
+int ovc_device_guard();
+
 static inline bool ovc_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 // ---- wave-level reductions (64 lanes) ------------------------------------------------------

@@ -123,7 +123,7 @@ bool model_ok(const ovc_model* m) {
     if ((m->d_feat & 3) || (m->d_ff & 3) || m->heads <= 0 || m->heads > 32 || m->heads * m->d_k > 1024 || m->vocab <= 1) return false;
     if (m->d_feat <= 0 || m->d_ff <= 0 || m->memory < 0) return false;
     if (m->max_len < 1 || m->max_len > 64) return false;
-    if (m->precision < 0 || m->precision > 4 || m->tune_objective < 0 || m->tune_objective > 8) return false;
+    if ((m->precision != 0 && m->precision != 3 && m->precision != 4) || m->tune_objective < 0 || m->tune_objective > 8) return false;
     if (m->bos_idx < 0 || m->bos_idx >= m->vocab || m->pad_idx < 0 || m->pad_idx >= m->vocab || m->eos_idx < 0 || m->eos_idx >= m->vocab) return false;
     // fused q|k|v and cross k|v GEMMs need segment widths that are multiples of the 64-wide tile
     if ((m->heads * m->d_k) % 64 || (m->heads * m->d_v) % 64 || (m->heads * m->d_k) != (m->heads * m->d_v)) return false;
@@ -543,7 +543,7 @@ int run_decode_step(Engine& e, Workspace& w, int B, int N, int k, int t, int ret
 
 }  // namespace
 
-extern "C" int ovc_abi_version(void) { return 5; }
+extern "C" int ovc_abi_version(void) { return 6; }
 
 extern "C" const char* ovc_build_info(void) {
     return "libovc gfx950 (CDNA4) fp32: v_mfma_f32_32x32x2_f32 GEMM + attention, HIP " __DATE__;
@@ -574,6 +574,7 @@ extern "C" int ovc_encode(const ovc_model* m, const float* features, const float
                           void* workspace, size_t workspace_bytes, float* enc_out, uint8_t* mask_out,
                           ovc_stream stream) {
     if (!model_ok(m) || !features || !workspace || !enc_out || !mask_out || B <= 0 || N <= 0 || N > 128) return OVC_EINVAL;
+    TRY(ovc_device_guard());
     if (!ovc_aligned16(features) || !ovc_aligned16(workspace) || !ovc_aligned16(enc_out)) return OVC_EINVAL;
     Workspace w = carve(m, workspace, B, N, 1, 0);
     if (w.bytes > workspace_bytes) return OVC_EWORKSPACE;
@@ -595,6 +596,7 @@ extern "C" int ovc_beam_search(const ovc_model* m, const float* features, const 
                                int out_size, void* workspace, size_t workspace_bytes, int64_t* ids_out,
                                float* logp_out, float* all_logp_out, ovc_stream stream) {
     if (!model_ok(m) || !features || !workspace || !ids_out || !logp_out) return OVC_EINVAL;
+    TRY(ovc_device_guard());
     if (B <= 0 || N <= 0 || N > 128 || k <= 0 || k > OVC_MAX_BEAM || out_size <= 0 || out_size > k) return OVC_EINVAL;
     if ((long)m->vocab < k) return OVC_EINVAL;
     if (!ovc_aligned16(features) || !ovc_aligned16(workspace)) return OVC_EINVAL;
@@ -691,6 +693,7 @@ extern "C" int ovc_beam_search_graph(const ovc_model* m, const float* features, 
                                      int out_size, void* workspace, size_t workspace_bytes, int64_t* ids_out,
                                      float* logp_out, ovc_stream stream) {
     if (!model_ok(m) || !features || !workspace || !ids_out || !logp_out) return OVC_EINVAL;
+    TRY(ovc_device_guard());
     if (B <= 0 || N <= 0 || N > 128 || k <= 0 || k > OVC_MAX_BEAM || out_size <= 0 || out_size > k) return OVC_EINVAL;
     if ((long)m->vocab < k) return OVC_EINVAL;
     if (!ovc_aligned16(features) || !ovc_aligned16(workspace)) return OVC_EINVAL;
@@ -714,6 +717,7 @@ extern "C" int ovc_beam_search_graph(const ovc_model* m, const float* features, 
     // Kernel nodes carry no stream, so the instantiated graph is launched on the caller's stream as usual.
     // (The legacy null stream can launch a graph but offers nothing else here; it takes the same path.)
     if (!entry.unsupported && !g_profile_on && entry.calls > 1 && !entry.exec) {
+        // one device per process (ovc_device_guard above): the capture stream belongs to the bound device
         static hipStream_t capture_stream = nullptr;          // guarded by g_graph_mutex
         if (!capture_stream && hipStreamCreateWithFlags(&capture_stream, hipStreamNonBlocking) != hipSuccess) {
             (void)hipGetLastError();

@@ -465,7 +465,7 @@ int launch_split_config(const GemmArgs& a, hipStream_t stream, const GemmLaunchO
 }
 
 // bm, bn, wm, wn, wk, bk, nc, planes.  fp32 tilings (planes = 0): chains = wk * nc is the K-order class the instance
-// belongs to; split-precision tilings (planes = the kernel's MODE: 1..3 bf16 planes, 4 = two fp16 planes): class
+// belongs to; split-precision tilings (planes = the kernel's MODE: 3 = three bf16 planes, 4 = two fp16 planes): class
 // 100 + MODE (kSplitClass).
 struct TilingInfo { int bm, bn, wm, wn, wk, bk, nc, planes; };
 constexpr int kSplitClass = 100;
@@ -488,17 +488,21 @@ constexpr int kSplitClass = 100;
 // deep K tiles for the M = B*k decode products: their MFMA block per K tile is a fraction of a microsecond, so a K loop is
 // a chain of load latencies and fewer, larger tiles halve it
 #define OVC_SPLIT_DEEP(X, first, planes) X(first + 0, 64, 64, 2, 2, 64, planes) X(first + 1, 64, 128, 2, 2, 64, planes)
-#define OVC_SPLIT_TILINGS(X) OVC_SPLIT_SHAPES(X, 17, 1) OVC_SPLIT_SHAPES(X, 22, 2) OVC_SPLIT_SHAPES(X, 27, 3) OVC_SPLIT_SHAPES(X, 32, 4) \
-    OVC_SPLIT_DEEP(X, 37, 1) OVC_SPLIT_DEEP(X, 39, 2) OVC_SPLIT_DEEP(X, 41, 3) OVC_SPLIT_DEEP(X, 43, 4)
+#define OVC_SPLIT_TILINGS(X) OVC_SPLIT_SHAPES(X, 17, 3) OVC_SPLIT_SHAPES(X, 22, 4) OVC_SPLIT_DEEP(X, 27, 3) OVC_SPLIT_DEEP(X, 29, 4)
 #define OVC_TILING_INFO(id, bm, bn, wm, wn, wk, bk, nc) {bm, bn, wm, wn, wk, bk, nc, 0},
 #define OVC_SPLIT_INFO(id, bm, bn, wm, wn, bk, planes) {bm, bn, wm, wn, 1, bk, 1, planes},
 constexpr TilingInfo kTilings[] = {OVC_TILINGS(OVC_TILING_INFO) OVC_SPLIT_TILINGS(OVC_SPLIT_INFO)};
 #undef OVC_TILING_INFO
 #undef OVC_SPLIT_INFO
 constexpr int kNumTilings = sizeof(kTilings) / sizeof(kTilings[0]);
-static_assert(kNumTilings == 45, "tiling ids: 17 fp32 + 28 split-precision");
+static_assert(kNumTilings == 31, "tiling ids: 17 fp32 + 14 split-precision (modes 3 and 4)");
 inline int tiling_chains(int t) { return kTilings[t].planes ? kSplitClass + kTilings[t].planes : kTilings[t].wk * kTilings[t].nc; }
-inline bool class_ok(int c) { return c == 1 || c == 4 || (c > kSplitClass && c <= kSplitClass + 4); }
+inline bool class_ok(int c) { return c == 1 || c == 4 || c == kSplitClass + 3 || c == kSplitClass + 4; }
+
+// One device per process (include/ovc.h): the library keeps per-process state that belongs to a device -- kernel attributes
+// raised once (dynamic LDS caps), the graph-capture stream, captured graphs, tuning tables.  The first launching call binds
+// the library to the device that is current then; a call made with another device current is refused, loudly.
+std::atomic<int> g_bound_device{-1};
 
 // Debug hook (ovc_debug_force_gemm_tiling): applies to every launch that does not carry its own
 // GemmLaunchOpts::forced_tiling and whose class matches; not for use while other threads decode.
@@ -509,7 +513,6 @@ std::atomic<int> g_forced_tiling{-1};
 struct TunedShape { int M, seg_n, nseg, K, kchains, ksplit, objective, tiling; };
 std::vector<TunedShape> g_tuned;
 std::mutex g_tuned_mutex;
-std::atomic<int> g_tune_copies{1};      // objective of ovc_gemm_tune: 1 = isolated latency, c > 1 = c co-running copies
 std::atomic<long> g_tune_calls{0};      // measurements actually run (tests assert that bucketed shapes re-use entries)
 
 // Exact entry, or (near = true) the entry of the same product whose M is closest within a factor of two: the best
@@ -566,6 +569,21 @@ bool tiling_fits(const GemmArgs& a, int t) {
 
 extern "C" size_t ovc_split_weight_bytes(int N, int K, int mode);
 
+int ovc_device_guard() {
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return OVC_ELAUNCH; }
+    int bound = g_bound_device.load(std::memory_order_relaxed);
+    if (bound < 0 && g_bound_device.compare_exchange_strong(bound, dev)) return OVC_OK;
+    return bound == dev ? OVC_OK : OVC_EDEVICE;
+}
+
+extern "C" int ovc_bound_device(void) { return g_bound_device.load(); }
+
+extern "C" int ovc_debug_rebind_device(int device) {
+    g_bound_device.store(device < 0 ? -1 : device);
+    return OVC_OK;
+}
+
 extern "C" int ovc_debug_force_gemm_tiling(int tiling) {
     if (tiling < -1 || tiling >= kNumTilings) return OVC_EINVAL;
     g_forced_tiling.store(tiling);
@@ -603,6 +621,7 @@ int ovc_gemm_pick_tiling(const GemmArgs& a, const GemmLaunchOpts& opts) {
 }
 
 int ovc_gemm_launch(const GemmArgs& a, hipStream_t stream, const GemmLaunchOpts& opts) {
+    if (const int rc = ovc_device_guard()) return rc;
     const int K = a.K1 + a.K2;
     if (a.M <= 0 || a.seg_n <= 0 || a.nseg <= 0 || a.nseg > OVC_MAX_SEGMENTS || K <= 0) return OVC_EINVAL;
     if (a.kchains != 0 && !class_ok(a.kchains)) return OVC_EINVAL;
@@ -643,8 +662,10 @@ int ovc_gemm_launch(const GemmArgs& a, hipStream_t stream, const GemmLaunchOpts&
 // Measure every tiling of one K-order class on one GEMM shape and remember the fastest (process-wide).  Synchronises
 // the stream: call it at set-up time, never inside a captured or latency-sensitive region.  The choice changes speed
 // only: all tilings of a class produce the same bits.
-extern "C" int ovc_gemm_tune(int M, int seg_n, int nseg, int K, int kchains, int ksplit, void* scratch, size_t scratch_bytes,
-                             ovc_stream stream) {
+extern "C" int ovc_gemm_tune(int M, int seg_n, int nseg, int K, int kchains, int ksplit, int objective, void* scratch,
+                             size_t scratch_bytes, ovc_stream stream) {
+    if (objective < 1 || objective > 8) return OVC_EINVAL;
+    if (const int rc = ovc_device_guard()) return rc;
     if (M <= 0 || seg_n <= 0 || nseg <= 0 || nseg > OVC_MAX_SEGMENTS || K <= 0 || (K & 3)) return OVC_EINVAL;
     if (!class_ok(kchains) || ksplit < 1 || ksplit > kMaxKSplit || (ksplit > 1 && (nseg != 1 || K % (ksplit * 32)))) return OVC_EINVAL;
     const size_t na = (size_t)M * K, nw = (size_t)seg_n * nseg * K, nc = (size_t)M * seg_n * nseg;
@@ -654,7 +675,6 @@ extern "C" int ovc_gemm_tune(int M, int seg_n, int nseg, int K, int kchains, int
     float* W = A + ((na + 3) & ~(size_t)3);
     float* C = W + ((nw + 3) & ~(size_t)3);
     if ((size_t)(C - A) + (size_t)ksplit * nc > scratch_bytes / sizeof(float)) return OVC_EWORKSPACE;
-    const int objective = g_tune_copies.load();
     if (tuned_lookup(M, seg_n, nseg, K, kchains, ksplit, objective, false) >= 0) return OVC_OK;
     GemmArgs a{};
     a.A1 = A; a.lda1 = K; a.K1 = K; a.M = M; a.seg_n = seg_n; a.nseg = nseg; a.ldc = seg_n; a.kchains = kchains;
@@ -696,28 +716,22 @@ extern "C" int ovc_gemm_tune(int M, int seg_n, int nseg, int K, int kchains, int
     return OVC_OK;
 }
 
-extern "C" int ovc_gemm_tune_objective(int copies) {
-    if (copies < 1 || copies > 8) return OVC_EINVAL;
-    g_tune_copies.store(copies);
-    return OVC_OK;
-}
-
 extern "C" long ovc_gemm_tune_calls(void) { return g_tune_calls.load(); }
 
 // Remembered tiling of a shape: -1 = nothing usable.  near != 0 also accepts the entry of the same product with the
 // closest M within a factor of two (what the launch path itself falls back to).
-extern "C" int ovc_gemm_tuned_get(int M, int seg_n, int nseg, int K, int kchains, int ksplit, int near) {
-    return tuned_lookup(M, seg_n, nseg, K, class_ok(kchains) ? kchains : 1, ksplit > 1 ? ksplit : 1, g_tune_copies.load(), near != 0);
+extern "C" int ovc_gemm_tuned_get(int M, int seg_n, int nseg, int K, int kchains, int ksplit, int objective, int near) {
+    return tuned_lookup(M, seg_n, nseg, K, class_ok(kchains) ? kchains : 1, ksplit > 1 ? ksplit : 1, objective > 1 ? objective : 1, near != 0);
 }
 
-extern "C" int ovc_gemm_tuned_set(int M, int seg_n, int nseg, int K, int kchains, int ksplit, int tiling) {
+extern "C" int ovc_gemm_tuned_set(int M, int seg_n, int nseg, int K, int kchains, int ksplit, int objective, int tiling) {
+    if (objective < 1 || objective > 8) return OVC_EINVAL;
     if (tiling < 0 || tiling >= kNumTilings || !class_ok(kchains) || ksplit < 1 || ksplit > kMaxKSplit) return OVC_EINVAL;
     if (M <= 0 || seg_n <= 0 || nseg <= 0 || nseg > OVC_MAX_SEGMENTS || K <= 0) return OVC_EINVAL;
     GemmArgs a{};
     a.M = M; a.seg_n = seg_n; a.nseg = nseg; a.K1 = K; a.kchains = kchains; a.ksplit = ksplit;
     if (ksplit > 1 && (nseg != 1 || K % (ksplit * 32))) return OVC_EINVAL;
     if (!tiling_fits(a, tiling)) return OVC_EINVAL;           // wrong class, tile straddling a segment, slice not a whole K tile
-    const int objective = g_tune_copies.load();
     const TunedShape entry{M, seg_n, nseg, K, kchains, ksplit, objective, tiling};
     std::lock_guard<std::mutex> lock(g_tuned_mutex);
     for (TunedShape& t : g_tuned)
@@ -761,9 +775,9 @@ __global__ __launch_bounds__(64) void split_weight_kernel(const float* __restric
 }
 }  // namespace
 
-// Bytes of the planes of a [N, K] weight in split-precision mode `mode` (1..4); 0 = invalid.
+// Bytes of the planes of a [N, K] weight in split-precision mode `mode` (3 or 4); 0 = invalid.
 extern "C" size_t ovc_split_weight_bytes(int N, int K, int mode) {
-    if (N <= 0 || K <= 0 || (K & 15) || mode < 1 || mode > 4) return 0;
+    if (N <= 0 || K <= 0 || (K & 15) || (mode != 3 && mode != 4)) return 0;
     return (size_t)((N + 31) / 32) * (K >> 4) * split_planes(mode) * 64 * 16;
 }
 
@@ -771,12 +785,8 @@ extern "C" int ovc_split_weight(const float* W, int N, int K, int mode, void* pl
     if (!W || !planes || !ovc_split_weight_bytes(N, K, mode) || !ovc_aligned16(planes)) return OVC_EINVAL;
     const dim3 grid(K >> 4, (N + 31) / 32);
     u32x4* out = reinterpret_cast<u32x4*>(planes);
-    switch (mode) {
-        case 1: hipLaunchKernelGGL(split_weight_kernel<1>, grid, dim3(64), 0, ovc_hip_stream(stream), W, N, K, out); break;
-        case 2: hipLaunchKernelGGL(split_weight_kernel<2>, grid, dim3(64), 0, ovc_hip_stream(stream), W, N, K, out); break;
-        case 3: hipLaunchKernelGGL(split_weight_kernel<3>, grid, dim3(64), 0, ovc_hip_stream(stream), W, N, K, out); break;
-        default: hipLaunchKernelGGL(split_weight_kernel<4>, grid, dim3(64), 0, ovc_hip_stream(stream), W, N, K, out); break;
-    }
+    if (mode == 3) hipLaunchKernelGGL(split_weight_kernel<3>, grid, dim3(64), 0, ovc_hip_stream(stream), W, N, K, out);
+    else hipLaunchKernelGGL(split_weight_kernel<4>, grid, dim3(64), 0, ovc_hip_stream(stream), W, N, K, out);
     OVC_RETURN_IF_LAUNCH_FAILED();
     return OVC_OK;
 }

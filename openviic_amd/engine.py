@@ -22,7 +22,8 @@ from . import native
 from .native import check
 
 
-# ovc_gemm_tune_objective selects the table the following tune / get / set calls act on: one such sequence at a time
+# one tiling measurement at a time per process (it synchronises the stream and shares one scratch buffer); the tuning
+# objective travels as an explicit argument of every tune / get / set call (ABI 6), not as process-wide state
 _TUNE_LOCK = threading.Lock()
 
 
@@ -106,12 +107,13 @@ class CaptionEngine:
     # pad the region axis to a multiple of this with zero rows before decoding (1 = exact shapes).  Results are
     # identical; with ragged real-data batches a bucket of 8 or 16 bounds the number of distinct shapes (graphs).
     region_bucket = int(os.environ.get("OVC_REGION_BUCKET", "1"))
-    # GEMM arithmetic: "f32" = fp32 MFMA, the parity mode (default, the only mode the headline numbers use).  Opt-in split
-    # precision: "bf16" / "bf16x3" / "bf16x6" cut every GEMM's fp32 operands into 1 / 2 / 3 bf16 planes and contract
-    # them on the 16-bit matrix path with fp32 accumulation (1 / 3 / 6 plane products); "f16x3" uses two fp16 planes
-    # (scaled residual, 3 products, 22 bits per operand) -- faster, fp32 in and out, but NOT bit-identical to "f32"
-    # (DESIGN.md has the measured token-id agreement of each mode).
-    PRECISIONS = {"f32": 0, "bf16": 1, "bf16x3": 2, "bf16x6": 3, "f16x3": 4}
+    # GEMM arithmetic: "f32" = fp32 MFMA, the parity mode (default, the only mode the headline numbers use).  Opt-in,
+    # uncredited split precision: "bf16x6" cuts every GEMM's fp32 operands into three bf16 planes and contracts them on
+    # the 16-bit matrix path with fp32 accumulation (6 plane products); "f16x3" uses two fp16 planes (scaled residual,
+    # 3 products, 22 bits per operand; operands beyond fp16's range saturate) -- faster, fp32 in and out, but NOT
+    # bit-identical to "f32" (DESIGN.md section 5a).  The one- and two-plane bf16 modes of round 2 failed the parity bar
+    # and were removed.
+    PRECISIONS = {"f32": 0, "bf16x6": 3, "f16x3": 4}
     # split-precision modes: cut every GEMM weight into its planes once (and again when it changes) instead of in every
     # workgroup of every launch -- same bits, W then bypasses conversion and LDS (OVC_PRECUT_WEIGHTS=0: A/B switch)
     precut_weights = os.environ.get("OVC_PRECUT_WEIGHTS", "1") != "0"
@@ -242,8 +244,7 @@ class CaptionEngine:
 
     def _tune_locked(self, B, N, k, objective):
         shapes = self.gemm_shapes(B, N, k)
-        # each objective has its own table in the library; the setting selects the one tuned_get / tune / tuned_set act on
-        check(self.lib.ovc_gemm_tune_objective(objective), "ovc_gemm_tune_objective")
+        # each objective has its own table in the library, named explicitly in every call below
         cache_path = os.environ.get("OVC_TUNE_CACHE")       # optional json: {"M,seg_n,nseg,K,kchains,ksplit@objective": tiling}
         cache = {}
         if cache_path and os.path.exists(cache_path):
@@ -252,8 +253,8 @@ class CaptionEngine:
             for shape in shapes:
                 name = ",".join(map(str, shape)) + "@%d" % objective
                 if name in cache:
-                    self.lib.ovc_gemm_tuned_set(*shape, int(cache[name]))
-        todo = [sh for sh in shapes if self.lib.ovc_gemm_tuned_get(*sh, 1) < 0]
+                    self.lib.ovc_gemm_tuned_set(*shape, objective, int(cache[name]))
+        todo = [sh for sh in shapes if self.lib.ovc_gemm_tuned_get(*sh, objective, 1) < 0]
         if todo:
             # operands + output (K-split shapes: one partial output per slice)
             # (+ room for pre-cut weight planes in the split-precision classes: the tuner then ranks the instances the engine runs)
@@ -261,12 +262,12 @@ class CaptionEngine:
                        (ns * self.lib.ovc_split_weight_bytes(sn, kk, kc - 100) if kc > 100 else 0) for m, sn, ns, kk, kc, ks in todo)
             scratch = torch.empty(need // 4 + 16, dtype=torch.float32, device=self.device).normal_()
             for sh in todo:
-                check(self.lib.ovc_gemm_tune(*sh, scratch.data_ptr(), scratch.numel() * 4, native.stream_handle()),
+                check(self.lib.ovc_gemm_tune(*sh, objective, scratch.data_ptr(), scratch.numel() * 4, native.stream_handle()),
                       "ovc_gemm_tune{}".format(sh))
             torch.cuda.current_stream().synchronize()
         if cache_path and todo:
             for shape in shapes:
-                t = self.lib.ovc_gemm_tuned_get(*shape, 0)
+                t = self.lib.ovc_gemm_tuned_get(*shape, objective, 0)
                 if t >= 0:
                     cache[",".join(map(str, shape)) + "@%d" % objective] = t
             os.makedirs(os.path.dirname(os.path.abspath(cache_path)), exist_ok=True)
@@ -312,7 +313,9 @@ class CaptionEngine:
         Fewer distinct N means fewer captured graphs when the region count varies from batch to batch."""
         bucket = max(1, int(self.region_bucket))
         N = features.shape[1]
-        target = min(128, -(-N // bucket) * bucket)
+        target = -(-N // bucket) * bucket
+        if target > 128:            # the bucket would pass the kernels' region limit: keep the exact shape (N > 128 then
+            target = N              # reaches ovc_workspace_bytes and raises -- padding is never allowed to crop)
         if target == N:
             return features, boxes
         pad = target - N

@@ -12,10 +12,11 @@ OVC_MAX_LAYERS = 8
 OVC_MAX_LEVELS = 4
 OVC_MAX_BEAM = 8
 OVC_PROFILE_CLASSES = 4
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 _ERRORS = {-1: "OVC_EINVAL (bad argument / unsupported shape)", -2: "OVC_EWORKSPACE (workspace too small)",
-           -3: "OVC_ELAUNCH (HIP launch failed)"}
+           -3: "OVC_ELAUNCH (HIP launch failed)",
+           -4: "OVC_EDEVICE (the library is bound to another device: one device per process)"}
 
 
 class OvcError(RuntimeError):
@@ -70,6 +71,8 @@ LIBRARY_PATH = os.environ.get("OVC_LIBRARY") or os.path.join(os.path.dirname(os.
 SIGNATURES = {
     "ovc_abi_version": (c_int, []),
     "ovc_build_info": (c_char_p, []),
+    "ovc_bound_device": (c_int, []),
+    "ovc_debug_rebind_device": (c_int, [c_int]),
     "ovc_linear": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int,
                            c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "ovc_layer_norm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_float,
@@ -90,11 +93,10 @@ SIGNATURES = {
     "ovc_encode": (c_int, [POINTER(Model), c_void_p, c_void_p, c_int, c_int, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]),
     "ovc_beam_search": (c_int, [POINTER(Model), c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_size_t,
                                 c_void_p, c_void_p, c_void_p, c_void_p]),
-    "ovc_gemm_tune": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
+    "ovc_gemm_tune": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "ovc_gemm_tune_calls": (c_long, []),
-    "ovc_gemm_tune_objective": (c_int, [c_int]),
-    "ovc_gemm_tuned_get": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
-    "ovc_gemm_tuned_set": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
+    "ovc_gemm_tuned_get": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
+    "ovc_gemm_tuned_set": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
     "ovc_engine_gemm_shapes": (c_int, [POINTER(Model), c_int, c_int, c_int, POINTER(c_int32), c_int]),
     "ovc_graph_cache_drop_workspace": (c_int, [c_void_p]),
     "ovc_graph_cache_size": (c_int, []),

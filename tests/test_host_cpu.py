@@ -189,6 +189,11 @@ def test_engine_limits_are_checked_before_anything_runs():
     assert size(_desc(n_levels=2, **meshed)) == 0                               # levels != encoder layers
     assert size(_desc(n_levels=3, dec_kind=native.DEC_MESHED)) == 0             # meshed decoder on a single-level encoder
     assert size(_desc(), N=129) == 0 and size(_desc(), k=9) == 0 and size(_desc(abi=1)) == 0
+    # GEMM arithmetic: fp32 (0) or the two opt-in modes that pass the parity bar (3 = bf16x6, 4 = f16x3); the one- and
+    # two-plane bf16 modes of ABI 5 were deleted
+    assert size(_desc(precision=3)) > 0 and size(_desc(precision=4)) > 0
+    assert size(_desc(precision=1)) == 0 and size(_desc(precision=2)) == 0 and size(_desc(precision=5)) == 0
+    assert lib.ovc_bound_device() == -1          # nothing has launched in this process: not bound to a device yet
 
 
 def test_engine_enumerates_its_gemm_shapes_with_fixed_k_order_classes():
@@ -237,3 +242,46 @@ def test_product_never_imports_the_oracle():
             if f.endswith(".py"):
                 text = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", text, re.M), os.path.join(dirpath, f)
+
+
+def test_region_bucket_pads_and_never_crops():
+    """`_bucketed` used to clamp the padded region count to 128 and hand F.pad a negative pad for
+    N > 128, which silently CROPS.  Padding may only ever add zero rows; N > 128 must reach ovc_workspace_bytes unchanged
+    (where it is refused: test_engine_limits_are_checked_before_anything_runs, and on the GPU
+    test_engine_gpu.py::test_more_than_128_regions_is_refused_whatever_the_bucket)."""
+    from openviic_amd.engine import CaptionEngine
+
+    class Stub:
+        region_bucket = 1
+    for bucket, n, want in ((1, 130, 130), (16, 129, 129), (16, 130, 130), (16, 120, 128), (16, 113, 128), (8, 37, 40),
+                            (16, 128, 128), (1, 50, 50), (16, 127, 128)):
+        Stub.region_bucket = bucket
+        feats, boxes = torch.randn(2, n, 4), torch.rand(2, n, 4)
+        got_f, got_b = CaptionEngine._bucketed(Stub, feats, boxes)
+        assert got_f.shape == (2, want, 4) and got_b.shape == (2, want, 4), (bucket, n, got_f.shape)
+        assert torch.equal(got_f[:, :n], feats) and torch.equal(got_b[:, :n], boxes)
+        assert not got_f[:, n:].any() and not got_b[:, n:].any()
+
+
+@pytest.mark.parametrize("variant", ["standard_transformer", "standard_transformer_using_region",
+                                     "meshed_memory_transformer", "object_relation_transformer"])
+def test_bench_reads_gemm_traffic_from_the_fp32_profile_of_its_workload(variant):
+    """bench.py's glob picked the f16x3 profile, whose GEMM rows belong to another kernel family,
+    and `roofline.traffic` came out null in the driver-run line.  The look-up must return numbers from a file of the
+    benchmarked architecture whose GEMM rows are gemm_f32_mfma, and must never pick an opt-in precision's file."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_module", os.path.join(REPO, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    per_launch, source, per_batch = bench.profiled_gemm_traffic(variant)
+    assert per_launch and per_batch and source, (variant, per_launch, source, per_batch)
+    assert 1e6 < per_launch < 1e9 and per_batch > per_launch
+    assert not any(tag in source for tag in bench.PROFILE_PRECISION_TAGS), source
+    tagged = [v for v in bench.PROFILE_VARIANT_TAGS if v in source]
+    assert tagged == ([] if variant.startswith("standard") else [variant]), source
+    rows = [r for r in __import__("csv").DictReader(open(os.path.join(REPO, "profiles", source)))]
+    assert any(r["kernel"].startswith("gemm_f32_mfma") for r in rows)
+    if variant.startswith("standard"):
+        assert bench.algorithmic_bytes(variant, 256) == 256 * (409600 + 614400 + 240) + 134.0e6
+    split, split_source, _ = bench.profiled_gemm_traffic("standard_transformer", "f16x3")
+    assert split is None or "f16x3" in split_source
