@@ -120,7 +120,10 @@ int main(int argc, char** argv) {
     const int M = argc > 4 ? atoi(argv[2]) : 8192, N = argc > 4 ? atoi(argv[3]) : 8192, K = argc > 4 ? atoi(argv[4]) : 2048;
     float *A, *W, *C, *h = (float*)malloc((size_t)M * K * 4);
     Stamp* st;
-    (void)hipMalloc(&A, (size_t)M * K * 4); (void)hipMalloc(&W, (size_t)N * K * 4); (void)hipMalloc(&C, (size_t)M * N * 4);
+    // the bare-MFMA mode reads 1024 x 256 x 8 floats of A and writes 1024 x 256 floats of C whatever the shape
+    const size_t a_floats = std::max((size_t)M * K, (size_t)1024 * 256 * 8), c_floats = std::max((size_t)M * N, (size_t)1024 * 256);
+    (void)hipMalloc(&A, a_floats * 4); (void)hipMalloc(&W, (size_t)N * K * 4); (void)hipMalloc(&C, c_floats * 4);
+    (void)hipMemset(A, 0, a_floats * 4);
     (void)hipMalloc(&st, 65536 * sizeof(Stamp));
     for (size_t i = 0; i < (size_t)M * K; ++i) h[i] = (float)rand() / RAND_MAX * 2.f - 1.f;
     (void)hipMemcpy(A, h, (size_t)M * K * 4, hipMemcpyHostToDevice);
