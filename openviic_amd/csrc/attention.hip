@@ -500,11 +500,205 @@ __global__ __launch_bounds__(256) void decode_self_attention_kernel(DecodeSelfAr
     }
 }
 
+// Per-image form with ancestor de-duplication (round 3).  The k beams of an image descend from one another: at step t
+// their histories name, per position j, only a few DISTINCT cache rows (measured on the BASELINE workload: 0.43 of the
+// k (t + 1) rows the per-row kernel above reads -- one copy per beam).  The rows a position can name are the image's own
+// width_j slots of that position's cache block (width_0 = 1, width_j = k), so the union is found with a k-bit mask per
+// position.  One workgroup per (image, 4 heads), one wave per head, no LDS for data -- the structure of the
+// cross-attention kernel below with a gathered key list:
+//   wave 0   lane j <= t ORs the local slots of the image's beams at position j into a mask, a wave scan turns the
+//            population counts into list offsets, and every (position, slot) that some beam names becomes one key
+//            n -> (j, l) of an LDS list (<= 16 NT entries), with its <pad> flag and each beam's slot per position
+//   S^T[key][beam] = K Q^T  on v_mfma_f32_16x16x4_f32, the beams as the 16-wide N dimension: every distinct key row is
+//            read once and scored against all beams; a (key, beam) pair counts only if the beam's history names that
+//            slot at that position (sl[beam][j] == l) -- the others get -inf, i.e. probability exactly 0
+//   softmax over the keys held in accumulator registers, O^T = V^T P^T with the probabilities as the B operand.
+// Key tiles past the end of the list are skipped with wave-uniform branches.  NT = key tiles the instance can hold
+// (worst case k (t + 1) keys, chosen by the host), SB = d_k / 16.
+template <int NT, int SB>
+__global__ __launch_bounds__(256) void decode_self_attention_mfma_kernel(DecodeSelfArgs p) {
+    __shared__ unsigned short keyinfo[NT * 16];          // (position << 3) | local slot
+    __shared__ uint8_t keypad[NT * 16];
+    __shared__ uint8_t sl[OVC_MAX_BEAM][64];             // local slot of beam i at position j
+    __shared__ int nkeys_shared;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = blockIdx.x, t = p.t, W = p.width;
+    const int hd = min((int)blockIdx.y * 4 + wave, p.h - 1);
+    const bool live = (int)blockIdx.y * 4 + wave < p.h;          // surplus waves redo the last head, store nothing
+    const int r = lane & 15, kq = lane >> 4;
+
+    // this wave's query fragments (independent of the key list: in flight while wave 0 builds it)
+    const float* qg = p.q + (size_t)(b * W + min(r, W - 1)) * p.ldq + hd * p.dk;
+    f32x4 qf[SB];
+#pragma unroll
+    for (int S = 0; S < SB; ++S) qf[S] = *reinterpret_cast<const f32x4*>(qg + 16 * S + 4 * kq);
+
+    if (wave == 0) {
+        const int j = lane;
+        const int wj = j == 0 ? 1 : W;                        // slots of position j's cache block that belong to this image
+        int slot[OVC_MAX_BEAM];
+        uint8_t pad[OVC_MAX_BEAM];
+        unsigned mask = 0;
+        if (j <= t) {
+#pragma unroll
+            for (int i = 0; i < OVC_MAX_BEAM; ++i)             // all loads first: ancestor slots and the block's <pad> flags
+                slot[i] = i < W ? (j == t ? i : p.anc[(size_t)(b * W + i) * p.anc_ld + j] - b * wj) : 0;
+#pragma unroll
+            for (int l = 0; l < OVC_MAX_BEAM; ++l) pad[l] = l < wj ? p.padflag[(size_t)j * p.pad_ld + b * wj + l] : 0;
+#pragma unroll
+            for (int i = 0; i < OVC_MAX_BEAM; ++i)
+                if (i < W) {
+                    const int s = min(max(slot[i], 0), wj - 1);   // a corrupt table can never index outside the image's block
+                    sl[i][j] = (uint8_t)s;
+                    mask |= 1u << s;
+                }
+        }
+        const int cnt = __popc(mask);
+        int incl = cnt;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int up = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += up;
+        }
+        int n = incl - cnt;
+#pragma unroll
+        for (int l = 0; l < OVC_MAX_BEAM; ++l)
+            if (mask & (1u << l)) {
+                if (n < NT * 16) { keyinfo[n] = (unsigned short)((j << 3) | l); keypad[n] = pad[l]; }
+                ++n;
+            }
+        if (lane == 63) nkeys_shared = min(incl, NT * 16);
+    }
+    __syncthreads();
+    const int nkeys = nkeys_shared;
+
+    // ---- K fragments of the listed keys: tile T holds keys 16 T .. 16 T + 15, lane r loads key 16 T + r -------------
+    f32x4 kf[NT][SB];
+#pragma unroll
+    for (int T = 0; T < NT; ++T) {
+        if (16 * T < nkeys) {                                  // wave-uniform
+            const int info = keyinfo[min(16 * T + r, nkeys - 1)];
+            const int j = info >> 3, l = info & 7;
+            const float* krow = p.kcache + (size_t)j * p.pos_stride + (size_t)(b * (j == 0 ? 1 : W) + l) * p.ldkv + hd * p.dk + 4 * kq;
+#pragma unroll
+            for (int S = 0; S < SB; ++S) kf[T][S] = *reinterpret_cast<const f32x4*>(krow + 16 * S);
+        }
+    }
+    if (r >= W) {
+#pragma unroll
+        for (int S = 0; S < SB; ++S) qf[S] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    f32x4 st[NT];
+#pragma unroll
+    for (int T = 0; T < NT; ++T) st[T] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int T = 0; T < NT; ++T) {
+        if (16 * T < nkeys) {
+#pragma unroll
+            for (int S = 0; S < SB; ++S)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) st[T] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[T][S][e], qf[S][e], st[T], 0, 0, 0);
+        }
+    }
+
+    // ---- V fragments (in flight during the softmax): lane (r, kq), register g <-> key 16 T + 4 kq + g, columns 4 r .. ----
+    const int vc = 4 * min(r, (p.dv >> 2) - 1);
+    f32x4 vf[NT][4];
+#pragma unroll
+    for (int T = 0; T < NT; ++T) {
+        if (16 * T < nkeys) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int info = keyinfo[min(16 * T + 4 * kq + g, nkeys - 1)];
+                const int j = info >> 3, l = info & 7;
+                vf[T][g] = *reinterpret_cast<const f32x4*>(p.vcache + (size_t)j * p.pos_stride +
+                                                           (size_t)(b * (j == 0 ? 1 : W) + l) * p.ldkv + hd * p.dv + vc);
+            }
+        }
+    }
+
+    // ---- scale, validity, softmax over the keys of this lane's beam column -------------------------------------------
+    const float scale_div = sqrtf((float)p.dk);
+    const int beam = min(r, W - 1);
+    float mx = -INFINITY;
+#pragma unroll
+    for (int T = 0; T < NT; ++T) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int key = 16 * T + 4 * kq + g;
+            float s = -INFINITY;
+            if (key < nkeys) {
+                const int info = keyinfo[key];
+                if (!keypad[key] && sl[beam][info >> 3] == (info & 7)) s = st[T][g] / scale_div;
+            }
+            st[T][g] = s;
+            mx = fmaxf(mx, s);
+        }
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int T = 0; T < NT; ++T)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float e = expf(st[T][g] - mx);
+            st[T][g] = e;
+            sum += e;
+        }
+    sum += __shfl_xor(sum, 16, 64);
+    sum += __shfl_xor(sum, 32, 64);
+#pragma unroll
+    for (int T = 0; T < NT; ++T)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) st[T][g] = st[T][g] / sum;
+
+    // ---- O^T = V^T P^T -----------------------------------------------------------------------------------------------
+    f32x4 acc[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[e] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int T = 0; T < NT; ++T) {
+        if (16 * T < nkeys) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[e] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[T][g][e], st[T][g], acc[e], 0, 0, 0);
+        }
+    }
+    if (live && r < W) {
+        float* orow = p.out + (size_t)(b * W + r) * p.ldo + hd * p.dv;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int dvb = 16 * kq + 4 * g;
+            if (dvb < p.dv) *reinterpret_cast<f32x4*>(orow + dvb) = f32x4{acc[0][g], acc[1][g], acc[2][g], acc[3][g]};
+        }
+    }
+}
+
 int ovc_decode_self_attention(const DecodeSelfArgs& p, int rows, hipStream_t stream) {
     const int hk = p.h * p.dk;
     if (p.t < 0 || p.t >= 64 || p.h <= 0 || p.h > kSelfMaxHeads) return OVC_EINVAL;
     if (p.dk != p.dv || (p.dk & (p.dk - 1)) || p.dk < 4 || p.dk > 64) return OVC_EINVAL;   // dk in {4,8,16,32,64}
     if (hk > 1024) return OVC_EINVAL;
+    // per-image kernel with ancestor de-duplication: the image's rows in one workgroup, at most 112 listed keys
+    static const bool per_row = getenv("OVC_SELF_ATTENTION_ROWS") != nullptr;     // A/B switch: the round-1 per-row kernel
+    const int W = p.width;
+    if (!per_row && W >= 1 && W <= OVC_MAX_BEAM && rows % W == 0 && p.dk >= 16 && (p.t == 0 ? 1 : W * (p.t + 1)) <= 112) {
+        const int worst = p.t == 0 ? 1 : W * (p.t + 1), tiles = (worst + 15) / 16;
+        const dim3 grid(rows / W, (p.h + 3) / 4), block(256);
+#define OVC_SELF(NT, SB) hipLaunchKernelGGL((decode_self_attention_mfma_kernel<NT, SB>), grid, block, 0, stream, p)
+#define OVC_SELF_NT(SB)                                                                                             \
+    do {                                                                                                            \
+        if (tiles <= 1) OVC_SELF(1, SB); else if (tiles <= 2) OVC_SELF(2, SB); else if (tiles <= 4) OVC_SELF(4, SB); \
+        else OVC_SELF(7, SB);                                                                                       \
+    } while (0)
+        if (p.dk == 64) OVC_SELF_NT(4); else if (p.dk == 32) OVC_SELF_NT(2); else OVC_SELF_NT(1);
+#undef OVC_SELF_NT
+#undef OVC_SELF
+        OVC_RETURN_IF_LAUNCH_FAILED();
+        return OVC_OK;
+    }
     if (hk <= 256) hipLaunchKernelGGL(decode_self_attention_kernel<1>, dim3(rows), dim3(256), 0, stream, p);
     else if (hk <= 512) hipLaunchKernelGGL(decode_self_attention_kernel<2>, dim3(rows), dim3(256), 0, stream, p);
     else hipLaunchKernelGGL(decode_self_attention_kernel<4>, dim3(rows), dim3(256), 0, stream, p);

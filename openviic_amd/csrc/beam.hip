@@ -63,7 +63,7 @@ __device__ __forceinline__ float wave_kth_largest(float v, int k) {
 // kMasked: the caller wants the masked log-probabilities of every word written out (return_probs); the hot path does
 // not, and then neither the stores nor their address arithmetic exist in the instruction stream.
 template <int kPerThread, int kVec, bool kMasked>
-__global__ __launch_bounds__(kSelThreads, (kPerThread * kVec <= 40 && !kMasked ? 5 : 1)) void beam_row_select_kernel(BeamSelectArgs p) {
+__global__ __launch_bounds__(kSelThreads, (kVec == 4 && kPerThread <= 10 && !kMasked ? 5 : 1)) void beam_row_select_kernel(BeamSelectArgs p) {
     constexpr int kElems = kPerThread * kVec;      // logits per thread; element (j, e) is column kVec*(tid + j*256) + e
     constexpr int kWaves = kSelThreads / 64;
     __shared__ float red[kWaves];
@@ -94,10 +94,14 @@ __global__ __launch_bounds__(kSelThreads, (kPerThread * kVec <= 40 && !kMasked ?
 
     const float* x = p.logits + (size_t)row * p.ld;
     const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, p.ld * 4, 0x00020000);
+    // Column of element (j, e) = cbase + 4 * 256 * j + e.  The index lives in ONE register: every section below adds its
+    // compile-time offsets on the fly, and an opaque copy per section keeps hipcc from computing all kElems indices once and
+    // holding them across the kernel (round 2: 40 index registers + 40 compare masks -> 4 spills at five waves per SIMD).
+    int cbase = kVec * tid;
+    const int jfull = V / (kVec * kSelThreads);     // vectors j < jfull lie below V for every thread: no tail mask (uniform)
     float xv[kElems];
 #pragma unroll
     for (int j = 0; j < kPerThread; ++j) {
-        const int c0 = kVec * (tid + j * kSelThreads);
         // unconditional loads from clamped (always valid) addresses; the tail is masked afterwards, so that all of
         // a thread's loads are in flight together (a guarded load costs a vmcnt(0) each)
         if (kVec == 4) {
@@ -106,10 +110,18 @@ __global__ __launch_bounds__(kSelThreads, (kPerThread * kVec <= 40 && !kMasked ?
             // 64-bit address registers, which is what keeps this kernel at five waves per SIMD
             const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, tid * 16, j * kSelThreads * 16, 0));
 #pragma unroll
-            for (int e = 0; e < 4; ++e) xv[j * 4 + e] = c0 + e < V ? v[e] : -INFINITY;
+            for (int e = 0; e < 4; ++e) xv[j * 4 + e] = v[e];
         } else {
-            const float v = x[min(c0, V - 1)];
-            xv[j] = c0 < V ? v : -INFINITY;
+            xv[j] = x[min(cbase + j * kSelThreads, V - 1)];
+        }
+    }
+    asm volatile("" : "+v"(cbase));
+#pragma unroll
+    for (int j = 0; j < kPerThread; ++j) {
+        if (j >= jfull) {                            // wave-uniform: only the vectors that can reach past V pay for the test
+#pragma unroll
+            for (int e = 0; e < kVec; ++e)
+                if (cbase + j * kVec * kSelThreads + e >= V) xv[j * kVec + e] = -INFINITY;
         }
     }
 
@@ -147,18 +159,20 @@ __global__ __launch_bounds__(kSelThreads, (kPerThread * kVec <= 40 && !kMasked ?
     float bv = -INFINITY;
     int bi = 0x7fffffff;
     float* mrow = kMasked ? p.masked_logp + (size_t)row * V : nullptr;
+    asm volatile("" : "+v"(cbase));
 #pragma unroll
     for (int j = 0; j < kElems; ++j) {
-        const int c = kVec * (tid + (j / kVec) * kSelThreads) + (j % kVec);
+        const int c = cbase + (j / kVec) * kVec * kSelThreads + (j % kVec);
         float cand = -INFINITY;
         if (c < V) {
             const float lp = (xv[j] - mx) - ls;
             if (kMasked) mrow[c] = lp * alive;
             cand = live ? run + lp : (c == 0 ? run : -999.0f);
-            if (cand > bv) { bv = cand; bi = i * V + c; }
+            if (cand > bv) { bv = cand; bi = c; }
         }
         xv[j] = cand;
     }
+    bi = bi == 0x7fffffff ? bi : i * V + bi;
 
     // ---- a lower bound on the row's k-th best: the k-th best of one wave's lane maxima (k distinct candidates
     //      are >= it), tightened by taking the largest such bound over the waves ---------------------------------------
@@ -173,12 +187,15 @@ __global__ __launch_bounds__(kSelThreads, (kPerThread * kVec <= 40 && !kMasked ?
     for (int w = 1; w < kWaves; ++w) T = fmaxf(T, thr[w]);
 
     // ---- survivors (score >= T; usually a few dozen) are appended to an LDS list -------------------------------------
+    asm volatile("" : "+v"(cbase));
 #pragma unroll
     for (int j = 0; j < kElems; ++j) {
-        const int c = kVec * (tid + (j / kVec) * kSelThreads) + (j % kVec);
-        if (c < V && xv[j] >= T) {
-            const int pos = atomicAdd(&count, 1);
-            if (pos < kSurvivorCap) { surv_v[pos] = xv[j]; surv_i[pos] = i * V + c; }
+        if (xv[j] >= T) {                            // tail elements hold -inf and T is a real candidate's score (or -inf: then checked)
+            const int c = cbase + (j / kVec) * kVec * kSelThreads + (j % kVec);
+            if (c < V) {
+                const int pos = atomicAdd(&count, 1);
+                if (pos < kSurvivorCap) { surv_v[pos] = xv[j]; surv_i[pos] = i * V + c; }
+            }
         }
     }
     __syncthreads();
@@ -188,16 +205,17 @@ __global__ __launch_bounds__(kSelThreads, (kPerThread * kVec <= 40 && !kMasked ?
         // log-probs are wanted).  Rare, so it is written for few registers rather than speed -- the register peak
         // of this kernel decides whether all B*k workgroups are resident at once: k rounds of a block-wide argmax
         // over the candidates that come after the previous pick in the (score desc, index asc) order.
+        // The candidates are recomputed from the logits in memory with the arithmetic of the register pass (same operands,
+        // same operations: the same bits), so that this path keeps none of the kElems registers or their indices alive.
         float pv = INFINITY;
         int pi = -1;
         for (int round = 0; round < k; ++round) {
             Cand c; c.v = -INFINITY; c.idx = 0x7fffffff;
-#pragma unroll
-            for (int j = 0; j < kElems; ++j) {
-                const int col = kVec * (tid + (j / kVec) * kSelThreads) + (j % kVec);
+            for (int col = tid; col < V; col += kSelThreads) {
+                const float cand = live ? run + ((x[col] - mx) - ls) : (col == 0 ? run : -999.0f);
                 const int idx = i * V + col;
-                const bool after = xv[j] < pv || (xv[j] == pv && idx > pi);
-                if (col < V && after && better(xv[j], idx, c.v, c.idx)) { c.v = xv[j]; c.idx = idx; }
+                const bool after = cand < pv || (cand == pv && idx > pi);
+                if (after && better(cand, idx, c.v, c.idx)) { c.v = cand; c.idx = idx; }
             }
             c = wave_best(c);
             __syncthreads();                   // the previous round's (or the survivor list's) readers are done

@@ -99,6 +99,8 @@ struct DecodeSelfArgs {
     const uint8_t* padflag;  // [T][pad_ld]    1 where the token fed at (position, slot) was <pad>
     int pad_ld;
     int t;                 // current position: keys 0..t (key t lives in the row's own slot)
+    int width;             // rows per image at this step (1 at t = 0, the beam size later): rows b * width .. + width - 1 are
+                           // image b's beams, and position j's cache block holds the image's slots b * width_j .. (width_0 = 1)
     int h, dk, dv;
     float* out;            // [rows, ldo]
     int ldo;

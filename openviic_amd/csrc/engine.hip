@@ -197,6 +197,14 @@ __global__ __launch_bounds__(256) void decode_embed_kernel(const int32_t* __rest
     for (int c = lane; c < (d >> 2); c += 64) o[c] = e[c] + p[c];
 }
 
+// Measurement hook (OVC_DEBUG_EXTRA_LAUNCHES=n): n empty launches behind every AddNorm LayerNorm of the decode step -- how much
+// does a kernel BOUNDARY cost the whole chip when several streams are in flight?  Never set in production.
+__global__ void noop_kernel() {}
+int extra_launches() {
+    static const int n = [] { const char* e = getenv("OVC_DEBUG_EXTRA_LAUNCHES"); return e ? atoi(e) : 0; }();
+    return n;
+}
+
 __global__ void init_beam_state_kernel(float* running, float* alive, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) { running[i] = 0.f; alive[i] = 1.f; }
@@ -307,7 +315,9 @@ struct Engine {
         a.seg[0] = seg(l, part); a.seg[0].bias = nullptr;     // raw partial products: bias applied by the consumer
         TRY(gemm(a));
         if (dry) return OVC_OK;
-        return ovc_layer_norm_parts(part, split, a.part_stride, l.b, residual, ln.g, ln.b, zero_rows, m->ln_eps, out, M, d, stream);
+        TRY(ovc_layer_norm_parts(part, split, a.part_stride, l.b, residual, ln.g, ln.b, zero_rows, m->ln_eps, out, M, d, stream));
+        for (int i = 0; i < extra_launches(); ++i) hipLaunchKernelGGL(noop_kernel, dim3(1), dim3(64), 0, stream);
+        return OVC_OK;
     }
 
     // AoA gate (attentions.py:311-315): out = W_i [q; x] * sigmoid(W_g [q; x]), one two-segment GEMM.
@@ -434,6 +444,10 @@ int run_decode_step(Engine& e, Workspace& w, int B, int N, int k, int t, int ret
 
     e.gemm_class = 2;
     e.kchains = 4;            // M = B*width products: four chains, so that 32x32 / 32x64 tiles can spread them over waves
+    {   // measurement hook: another K-order class for the decode-step products (changes low-order bits; never set in production)
+        static const int forced = [] { const char* v = getenv("OVC_DEBUG_DECODE_KCHAINS"); return v ? atoi(v) : 0; }();
+        if (forced == 1 || forced == 4) e.kchains = forced;
+    }
     float* x = w.x;
     for (int l = 0; l < m->n_dec; ++l) {
         const ovc_dec_layer& dl = m->dec[l];
@@ -448,7 +462,7 @@ int run_decode_step(Engine& e, Workspace& w, int B, int N, int k, int t, int ret
         TRY(e.gemm(a));
         DecodeSelfArgs sa{};
         sa.q = w.q; sa.ldq = hk; sa.kcache = kc; sa.vcache = vc; sa.pos_stride = (size_t)R * hk; sa.ldkv = hk;
-        sa.anc = w.anc[cur]; sa.anc_ld = T; sa.padflag = w.padflag; sa.pad_ld = R; sa.t = t;
+        sa.anc = w.anc[cur]; sa.anc_ld = T; sa.padflag = w.padflag; sa.pad_ld = R; sa.t = t; sa.width = width;
         sa.h = m->heads; sa.dk = m->d_k; sa.dv = m->d_v; sa.out = w.att; sa.ldo = hv;
         RUN(ovc_decode_self_attention(sa, rows, s));
         TRY(e.linear_ln(w.att, hv, dl.self_att.o, x, dl.self_att.ln, nullptr, w.y, w.part, w.x1, rows));

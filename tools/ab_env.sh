@@ -1,9 +1,12 @@
 #!/bin/bash
-# A/B timing of a run-time switch on ONE box:  tools/ab_env.sh VAR [rounds]   (VAR=0 against VAR unset)
+# A/B timing of a run-time switch on ONE box:  tools/ab_env.sh VAR [rounds] [streams...]   (VAR=0 against VAR unset)
+# Prints the fp32 headline line of each run ("[bench] gpu: ... captions/s"), alternating on / off.
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
-for i in $(seq 1 ${2:-2}); do
-  for S in 4 1; do
-    echo -n "on   streams=$S: "; python3 $ROOT/bench.py --no-cpu-baseline --streams $S 2>&1 >/dev/null | tail -1 | cut -c1-90
-    echo -n "off  streams=$S: "; env $1=0 python3 $ROOT/bench.py --no-cpu-baseline --streams $S 2>&1 >/dev/null | tail -1 | cut -c1-90
+VAR=$1; ROUNDS=${2:-2}; shift; shift
+STREAMS=${@:-4 1}
+for i in $(seq 1 $ROUNDS); do
+  for S in $STREAMS; do
+    echo -n "unset streams=$S: "; python3 $ROOT/bench.py --no-cpu-baseline --also-precision none --streams $S $AB_ARGS 2>&1 >/dev/null | grep "\[bench\] gpu:" | cut -c1-100
+    echo -n "$VAR=0 streams=$S: "; env $VAR=0 python3 $ROOT/bench.py --no-cpu-baseline --also-precision none --streams $S $AB_ARGS 2>&1 >/dev/null | grep "\[bench\] gpu:" | cut -c1-100
   done
 done

@@ -1,0 +1,11 @@
+#!/bin/bash
+# A/B of one environment setting on ONE box:  tools/ab_envval.sh "VAR=value" [rounds] [streams...]   (set against unset)
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+SET=$1; ROUNDS=${2:-2}; shift; shift
+STREAMS=${@:-4 1}
+for i in $(seq 1 $ROUNDS); do
+  for S in $STREAMS; do
+    echo -n "unset      streams=$S: "; python3 $ROOT/bench.py --no-cpu-baseline --also-precision none --streams $S $AB_ARGS 2>&1 >/dev/null | grep "\[bench\] gpu:" | cut -c1-100
+    echo -n "$SET streams=$S: "; env $SET python3 $ROOT/bench.py --no-cpu-baseline --also-precision none --streams $S $AB_ARGS 2>&1 >/dev/null | grep "\[bench\] gpu:" | cut -c1-100
+  done
+done
