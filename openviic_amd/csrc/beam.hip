@@ -334,33 +334,12 @@ __global__ __launch_bounds__(64) void beam_merge_kernel(BeamSelectArgs p) {
 // 256 threads per image: wave 0 merges the candidates and writes the per-beam scalars, then all four waves move the
 // histories and build the next step's input rows with every load issued before the first store (the single-wave version
 // walked ten dependent load -> store round trips for the embedding rows alone: 9.7 us).
-__global__ __launch_bounds__(256) void beam_update_kernel(BeamUpdateArgs p) {
-    const int b = blockIdx.x, tid = threadIdx.x;
-    const int k = p.k, W = p.width, V = p.V, T = p.T, t = p.t;
-    __shared__ int parent[kMaxK], word[kMaxK];
-    if (tid < 64) {
-        const Cand best = merge_row_candidates(p.cand_v, p.cand_i, b, W, k, tid);
-        if (tid < k) {
-            // An image without a single valid region (all-zero features, e.g. the padding images of a ragged last shard)
-            // has every key masked: its logits are NaN, no candidate compares greater than anything and no winner
-            // exists.  The reference returns arbitrary in-range words for it; here slot j takes word j of beam 0, so
-            // that every index derived from it stays in range.
-            const int f = (unsigned)best.idx < (unsigned)(W * V) ? best.idx : tid;
-            const int par = f / V, wd = f - par * V;
-            parent[tid] = par; word[tid] = wd;
-            const float alive = p.alive_in[b * W + par];
-            const float x = p.logits[((size_t)b * W + par) * p.ld + wd];
-            const float lp = ((x - p.row_max[b * W + par]) - p.row_lsum[b * W + par]) * alive;
-            p.running_out[b * k + tid] = best.v;
-            p.alive_out[b * k + tid] = alive * (wd != p.eos ? 1.0f : 0.0f);
-            p.hist_out[((size_t)b * k + tid) * T + t] = wd;
-            p.lp_out[((size_t)b * k + tid) * T + t] = lp;
-            p.next_tok[b * k + tid] = wd;
-            p.anc_out[((size_t)b * k + tid) * T + t] = b * W + par;
-        }
-    }
-    __syncthreads();
-    for (int idx = tid; idx < k * t; idx += 256) {
+// Everything that follows the choice of the image's k winners (parent[j], word[j] in LDS, visible to all threads): the
+// histories / per-token log-probs / ancestor slots follow the selected beams, and the next step's input rows are built.
+template <int kThreads>
+__device__ __forceinline__ void beam_follow_winners(const BeamUpdateArgs& p, int b, int tid, const int* parent, const int* word) {
+    const int k = p.k, W = p.width, T = p.T, t = p.t;
+    for (int idx = tid; idx < k * t; idx += kThreads) {
         const int j = idx / t, pos = idx - j * t;
         const size_t src = ((size_t)b * W + parent[j]) * T + pos, dst = ((size_t)b * k + j) * T + pos;
         const int32_t hv = p.hist_in[src];
@@ -375,19 +354,19 @@ __global__ __launch_bounds__(256) void beam_update_kernel(BeamUpdateArgs p) {
     if (p.next_x) {
         const int nvec = p.d_model >> 2, total = k * nvec;
         const f32x4* __restrict__ pos = reinterpret_cast<const f32x4*>(p.pos_emb + (size_t)(t + 2) * p.d_model);
-        constexpr int kUnroll = 4;                         // 4 x 256 float4 in flight per pass: k * d_model <= 4096 in one pass
-        for (int base = tid; base < total; base += 256 * kUnroll) {
+        constexpr int kUnroll = 1024 / kThreads;           // 1024 float4 in flight per pass: k * d_model <= 4096 in one pass
+        for (int base = tid; base < total; base += kThreads * kUnroll) {
             f32x4 ev[kUnroll], pv[kUnroll];
 #pragma unroll
             for (int u = 0; u < kUnroll; ++u) {
-                const int idx = min(base + u * 256, total - 1);
+                const int idx = min(base + u * kThreads, total - 1);
                 const int j = idx / nvec, c = idx - j * nvec;
                 ev[u] = reinterpret_cast<const f32x4*>(p.word_emb + (size_t)word[j] * p.d_model)[c];
                 pv[u] = pos[c];
             }
 #pragma unroll
             for (int u = 0; u < kUnroll; ++u) {
-                const int idx = base + u * 256;
+                const int idx = base + u * kThreads;
                 if (idx < total) {
                     const int j = idx / nvec, c = idx - j * nvec;
                     reinterpret_cast<f32x4*>(p.next_x + ((size_t)b * k + j) * p.d_model)[c] = ev[u] + pv[u];
@@ -396,6 +375,265 @@ __global__ __launch_bounds__(256) void beam_update_kernel(BeamUpdateArgs p) {
         }
         if (tid < k) p.next_padflag[b * k + tid] = word[tid] == p.pad ? 1 : 0;
     }
+}
+
+// The per-beam scalars of winner `slot` (flat index f = beam * V + word, score v) of image b.
+// row_max / row_lsum: the log-softmax pieces of the image's rows, indexed by the beam inside the image.
+__device__ __forceinline__ void beam_record_winner(const BeamUpdateArgs& p, int b, int slot, int best_idx, float best_v,
+                                                   const float* row_max, const float* row_lsum, int* parent, int* word) {
+    const int k = p.k, W = p.width, V = p.V, T = p.T, t = p.t;
+    // An image without a single valid region (all-zero features, e.g. the padding images of a ragged last shard)
+    // has every key masked: its logits are NaN, no candidate compares greater than anything and no winner
+    // exists.  The reference returns arbitrary in-range words for it; here slot j takes word j of beam 0, so
+    // that every index derived from it stays in range.
+    const int f = (unsigned)best_idx < (unsigned)(W * V) ? best_idx : slot;
+    const int par = f / V, wd = f - par * V;
+    parent[slot] = par; word[slot] = wd;
+    const float alive = p.alive_in[b * W + par];
+    const float x = p.logits[((size_t)b * W + par) * p.ld + wd];
+    const float lp = ((x - row_max[par]) - row_lsum[par]) * alive;
+    p.running_out[b * k + slot] = best_v;
+    p.alive_out[b * k + slot] = alive * (wd != p.eos ? 1.0f : 0.0f);
+    p.hist_out[((size_t)b * k + slot) * T + t] = wd;
+    p.lp_out[((size_t)b * k + slot) * T + t] = lp;
+    p.next_tok[b * k + slot] = wd;
+    p.anc_out[((size_t)b * k + slot) * T + t] = b * W + par;
+}
+
+__global__ __launch_bounds__(256) void beam_update_kernel(BeamUpdateArgs p) {
+    const int b = blockIdx.x, tid = threadIdx.x;
+    __shared__ int parent[kMaxK], word[kMaxK];
+    if (tid < 64) {
+        const Cand best = merge_row_candidates(p.cand_v, p.cand_i, b, p.width, p.k, tid);
+        if (tid < p.k) beam_record_winner(p, b, tid, best.idx, best.v, p.row_max + b * p.width, p.row_lsum + b * p.width, parent, word);
+    }
+    __syncthreads();
+    beam_follow_winners<256>(p, b, tid, parent, word);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Selection WITHOUT reading the logits back (round 3).  The vocabulary GEMM's epilogue leaves, per beam row and 32-column
+// block, the block's maximum and sum exp(x - maximum) (GemmArgs::stats, block-major [nblk][rows]).  One workgroup per image:
+//   A  the row's log-softmax pieces from its nblk pairs: M = max of the block maxima, S = sum_b s_b exp(m_b - M) in a fixed
+//      order, ls = log S -- the same M the full pass finds, ls to rounding;
+//   B  every block's maximum IS a candidate: u_b = run + ((m_b - M) - ls) is the score of the block's best word, computed
+//      with the arithmetic of the per-word pass.  The k-th largest of one wave's lane maxima of u bounds the image's k-th
+//      best from below (k distinct candidates reach it);
+//   C  only blocks with u_b >= that bound can hold a winner ("hot" blocks: a handful); their 32 logits are read, scored and
+//      the survivors ranked by counting (score descending, lower flat index first: the tie rule of the two-pass path);
+//      a frozen beam contributes its k fixed candidates (word 0 at its running score, -999 for words 1..k-1) directly;
+//   D  the bookkeeping of beam_update_kernel.
+// 160 pairs per row instead of 10 201 logits; one launch instead of two.  Massive ties (a uniform row: every block hot)
+// overflow the lists and take k rounds of an exhaustive arg-max over the image's width * V candidates.
+constexpr int kHotCap = 512, kFusedSurvCap = 1024, kFusedThreads = 512, kFusedPairs = 4;   // 64 lanes x 4 loads x 2 blocks = 512 blocks
+
+// 512 threads per image: wave w < width owns beam row w through phases A and B (no workgroup-level reduction), then all
+// eight waves gather the hot blocks and wave 0 ranks the survivors in registers.
+__global__ __launch_bounds__(kFusedThreads) void beam_fused_update_kernel(BeamUpdateArgs p, const float* __restrict__ stats, int nblk,
+                                                                          int stats_ld, const float* __restrict__ running_in) {
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int W = p.width, k = p.k, V = p.V, T = p.T, t = p.t;
+    __shared__ float rowM[kMaxK], rowLs[kMaxK], rowRun[kMaxK], thr[kMaxK];
+    __shared__ int rowLive[kMaxK];
+    __shared__ int nhot, nsurv;
+    __shared__ unsigned short hot_blk[kHotCap];
+    __shared__ uint8_t hot_row[kHotCap];
+    __shared__ float surv_v[kFusedSurvCap], surv_x[kFusedSurvCap];
+    __shared__ int surv_i[kFusedSurvCap];
+    __shared__ float win_v[kMaxK], win_x[kMaxK];
+    __shared__ int win_i[kMaxK];
+    __shared__ int parent[kMaxK], word[kMaxK];
+
+    if (tid == 0) { nhot = 0; nsurv = 0; }
+    if (tid < kMaxK) { win_v[tid] = -INFINITY; win_i[tid] = 0x7fffffff; win_x[tid] = 0.f; }
+    // ---- A + B: wave w = beam row w.  Lane l holds the block pairs l + 64 j (four 16-byte loads per lane, 1 KB per wave and
+    //      load, all in flight together); log-softmax pieces, block bounds and the row's own k-th best bound by wave-level
+    //      reductions only ---------------------------------------------------------------------------------------------------
+    f32x4 st[kFusedPairs];
+    float ub[kFusedPairs][2];
+    float run = 0.f;
+    bool live = false;
+    if (wave < W) {
+        const int row = b * W + wave;
+        const float* srow = stats + 2 * (size_t)row * stats_ld;
+#pragma unroll
+        for (int j = 0; j < kFusedPairs; ++j)      // unconditional loads from clamped addresses, masked below
+            st[j] = *reinterpret_cast<const f32x4*>(srow + 2 * min(2 * (lane + 64 * j), stats_ld - 2));
+        run = running_in[row];
+        live = p.alive_in[row] != 0.0f;
+        float m = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < kFusedPairs; ++j) {
+            const int blk0 = 2 * (lane + 64 * j);
+            if (blk0 >= nblk) { st[j][0] = -INFINITY; st[j][1] = 0.f; }
+            if (blk0 + 1 >= nblk) { st[j][2] = -INFINITY; st[j][3] = 0.f; }
+            m = fmaxf(m, fmaxf(st[j][0], st[j][2]));
+        }
+        const float M = wave_max_dpp(m);
+        float sum = 0.f;
+#pragma unroll
+        for (int j = 0; j < kFusedPairs; ++j)      // a block past nblk holds (-inf, 0): 0 * exp(-inf) = 0
+            sum += st[j][1] * __expf(st[j][0] - M) + st[j][3] * __expf(st[j][2] - M);
+        const float ls = logf(wave_sum_dpp(sum));
+        float lanemax = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < kFusedPairs; ++j) {
+            const int blk0 = 2 * (lane + 64 * j);
+            // every block's maximum IS a candidate: its score, with the arithmetic of the per-word pass
+            ub[j][0] = live && blk0 < nblk ? run + ((st[j][0] - M) - ls) : -INFINITY;
+            ub[j][1] = live && blk0 + 1 < nblk ? run + ((st[j][2] - M) - ls) : -INFINITY;
+            lanemax = fmaxf(lanemax, fmaxf(ub[j][0], ub[j][1]));
+        }
+        // k distinct candidates of this row reach the k-th largest lane maximum: a lower bound on the image's k-th best
+        const float kth = wave_kth_largest(lanemax, k);
+        if (lane == 0) {
+            rowM[wave] = M; rowLs[wave] = ls; rowRun[wave] = run; rowLive[wave] = live ? 1 : 0; thr[wave] = kth;
+            if (p.row_max_out) { p.row_max_out[row] = M; p.row_lsum_out[row] = ls; }
+        }
+    }
+    __syncthreads();
+    float Tthr = -INFINITY;
+    for (int i = 0; i < W; ++i) Tthr = fmaxf(Tthr, thr[i]);
+
+    // ---- C: hot blocks -> survivors -> ranks ------------------------------------------------------------------------------
+    if (wave < W) {
+#pragma unroll
+        for (int j = 0; j < kFusedPairs; ++j)
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+                if (ub[j][u] > -INFINITY && ub[j][u] >= Tthr) {
+                    const int pos = atomicAdd(&nhot, 1);
+                    if (pos < kHotCap) { hot_blk[pos] = (unsigned short)(2 * (lane + 64 * j) + u); hot_row[pos] = (uint8_t)wave; }
+                }
+        // a frozen beam (it has emitted <eos>) offers word 0 at its running score and -999 for every other word
+        // (beam_search.py:52-55): its k best are words 0..k-1, whatever the logits are
+        if (!live && lane < k && lane < V) {
+            const int pos = atomicAdd(&nsurv, 1);                                          // pos < k * k <= the cap
+            surv_v[pos] = lane == 0 ? run : -999.0f; surv_i[pos] = wave * V + lane; surv_x[pos] = 0.f;
+        }
+    }
+    __syncthreads();
+    const int H = nhot;
+    bool exhaustive = H > kHotCap;
+    if (!exhaustive) {
+        // 16 hot blocks per pass; the loads of up to four passes are issued before the first survivor is appended
+        constexpr int kPasses = 4, kPerPass = kFusedThreads / 32;
+        for (int h0 = 0; h0 < H; h0 += kPasses * kPerPass) {
+            float x[kPasses];
+            int ri[kPasses], col[kPasses];
+#pragma unroll
+            for (int u = 0; u < kPasses; ++u) {
+                const int h = min(h0 + u * kPerPass + (tid >> 5), H - 1);
+                ri[u] = hot_row[h];
+                col[u] = min(hot_blk[h] * 32 + (tid & 31), V - 1);
+                x[u] = p.logits[((size_t)b * W + ri[u]) * p.ld + col[u]];
+            }
+#pragma unroll
+            for (int u = 0; u < kPasses; ++u) {
+                const int h = h0 + u * kPerPass + (tid >> 5);
+                if (h < H && hot_blk[h] * 32 + (tid & 31) < V) {
+                    const float cand = rowRun[ri[u]] + ((x[u] - rowM[ri[u]]) - rowLs[ri[u]]);
+                    if (cand >= Tthr) {
+                        const int pos = atomicAdd(&nsurv, 1);
+                        if (pos < kFusedSurvCap) { surv_v[pos] = cand; surv_i[pos] = ri[u] * V + col[u]; surv_x[pos] = x[u]; }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        exhaustive = nsurv > kFusedSurvCap;
+    }
+    if (!exhaustive) {
+        const int ns = nsurv;
+        if (ns <= 64) {
+            // the usual case: wave 0 ranks in registers -- lane e holds survivor e and counts the survivors that beat it
+            // (score descending, lower flat index first: a strict total order, so ranks are unique)
+            if (wave == 0) {
+                const float v = lane < ns ? surv_v[lane] : -INFINITY;
+                const int idx = lane < ns ? surv_i[lane] : 0x7fffffff;
+                int rank = 0;
+                for (int o = 0; o < ns; ++o) {
+                    const float ov = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), o));
+                    const int oi = __builtin_amdgcn_readlane(idx, o);
+                    rank += better(ov, oi, v, idx) ? 1 : 0;
+                }
+                if (lane < ns && rank < k) { win_v[rank] = v; win_i[rank] = idx; win_x[rank] = surv_x[lane]; }
+            }
+        } else {
+            for (int e = tid; e < ns; e += kFusedThreads) {
+                const float v = surv_v[e];
+                const int idx = surv_i[e];
+                int rank = 0;
+                for (int o = 0; o < ns; ++o) rank += better(surv_v[o], surv_i[o], v, idx) ? 1 : 0;
+                if (rank < k) { win_v[rank] = v; win_i[rank] = idx; win_x[rank] = surv_x[e]; }
+            }
+        }
+    } else {
+        // massive ties: k rounds of a block-wide arg-max over the candidates that come after the previous pick in the
+        // (score descending, flat index ascending) order; rare, written for simplicity
+        float pv = INFINITY;
+        int pi = -1;
+        for (int round = 0; round < k; ++round) {
+            Cand c; c.v = -INFINITY; c.idx = 0x7fffffff;
+            float cx = 0.f;
+            for (int i = 0; i < W; ++i) {
+                const float* x = p.logits + ((size_t)b * W + i) * p.ld;
+                const float ri = rowRun[i], mi = rowM[i], li = rowLs[i];
+                const bool alive_i = rowLive[i] != 0;
+                for (int col = tid; col < V; col += kFusedThreads) {
+                    const float xc = x[col];
+                    const float cand = alive_i ? ri + ((xc - mi) - li) : (col == 0 ? ri : -999.0f);
+                    const int idx = i * V + col;
+                    const bool after = cand < pv || (cand == pv && idx > pi);
+                    if (after && better(cand, idx, c.v, c.idx)) { c.v = cand; c.idx = idx; cx = xc; }
+                }
+            }
+            const Cand wbest = wave_best(c);
+            __syncthreads();
+            if (c.idx == wbest.idx && wbest.idx != 0x7fffffff) { surv_v[wave] = c.v; surv_i[wave] = c.idx; surv_x[wave] = cx; }   // unique owner
+            if (lane == 0 && wbest.idx == 0x7fffffff) { surv_v[wave] = -INFINITY; surv_i[wave] = 0x7fffffff; surv_x[wave] = 0.f; }
+            __syncthreads();
+            int best_w = 0;
+#pragma unroll
+            for (int w = 1; w < kFusedThreads / 64; ++w)
+                if (better(surv_v[w], surv_i[w], surv_v[best_w], surv_i[best_w])) best_w = w;
+            pv = surv_v[best_w]; pi = surv_i[best_w];
+            if (tid == 0) { win_v[round] = pv; win_i[round] = pi; win_x[round] = surv_x[best_w]; }
+        }
+    }
+    __syncthreads();
+
+    // ---- D: bookkeeping (beam_update_kernel's, with the winner's logit carried along instead of re-read) -------------------
+    if (tid < k) {
+        const int f = (unsigned)win_i[tid] < (unsigned)(W * V) ? win_i[tid] : tid;      // no winner (NaN scores): as beam_record_winner
+        const int par = f / V, wd = f - par * V;
+        parent[tid] = par; word[tid] = wd;
+        const float alive = rowLive[par] ? p.alive_in[b * W + par] : 0.0f;
+        // the carried logit is the winner's own; without a winner, or for a frozen beam's fixed candidates (whose product with
+        // alive = 0 only needs a finite operand), the logit is read as the two-pass path reads it
+        const float x = ((unsigned)win_i[tid] < (unsigned)(W * V) && rowLive[par]) ? win_x[tid] : p.logits[((size_t)b * W + par) * p.ld + wd];
+        const float lp = ((x - rowM[par]) - rowLs[par]) * alive;
+        p.running_out[b * k + tid] = win_v[tid];
+        p.alive_out[b * k + tid] = alive * (wd != p.eos ? 1.0f : 0.0f);
+        p.hist_out[((size_t)b * k + tid) * T + t] = wd;
+        p.lp_out[((size_t)b * k + tid) * T + t] = lp;
+        p.next_tok[b * k + tid] = wd;
+        p.anc_out[((size_t)b * k + tid) * T + t] = b * W + par;
+    }
+    __syncthreads();
+    beam_follow_winners<kFusedThreads>(p, b, tid, parent, word);
+}
+
+// masked_logp[row, c] = ((x - row_max) - row_lsum) * alive for every word (return_probs; beam_search.py:68-72) from the
+// row pieces beam_fused_update_kernel published -- the values its decisions were taken on.
+__global__ __launch_bounds__(256) void masked_logp_kernel(const float* __restrict__ logits, int ld, const float* __restrict__ row_max,
+                                                          const float* __restrict__ row_lsum, const float* __restrict__ alive, int V,
+                                                          float* __restrict__ out) {
+    const int row = blockIdx.x;
+    const float m = row_max[row], l = row_lsum[row], a = alive ? alive[row] : 1.0f;
+    const float* x = logits + (size_t)row * ld;
+    float* y = out + (size_t)row * V;
+    for (int c = threadIdx.x; c < V; c += 256) y[c] = ((x[c] - m) - l) * a;
 }
 
 // Final ordering (beam_search.py:97-113): beams sorted by total score, descending, stable.
@@ -471,6 +709,23 @@ int ovc_beam_select_launch(const BeamSelectArgs& p, int B, hipStream_t stream) {
 
 int ovc_beam_update_launch(const BeamUpdateArgs& p, int B, hipStream_t stream) {
     hipLaunchKernelGGL(beam_update_kernel, dim3(B), dim3(256), 0, stream, p);
+    OVC_RETURN_IF_LAUNCH_FAILED();
+    return OVC_OK;
+}
+
+int ovc_beam_fused_update_launch(const BeamUpdateArgs& p, const float* stats, int nblk, int stats_ld, const float* running_in,
+                                 int B, hipStream_t stream) {
+    if (B <= 0 || p.width <= 0 || p.width > kMaxK || p.k <= 0 || p.k > kMaxK || p.V <= 0 || !stats || !running_in) return OVC_EINVAL;
+    if (nblk != (p.V + 31) / 32 || nblk > 512 || stats_ld < nblk || (stats_ld & 1) || !ovc_aligned16(stats)) return OVC_EINVAL;
+    if ((long)p.width * p.V < p.k) return OVC_EINVAL;
+    hipLaunchKernelGGL(beam_fused_update_kernel, dim3(B), dim3(kFusedThreads), 0, stream, p, stats, nblk, stats_ld, running_in);
+    OVC_RETURN_IF_LAUNCH_FAILED();
+    return OVC_OK;
+}
+
+int ovc_masked_logp_launch(const float* logits, int ld, const float* row_max, const float* row_lsum, const float* alive, int rows, int V,
+                           float* out, hipStream_t stream) {
+    hipLaunchKernelGGL(masked_logp_kernel, dim3(rows), dim3(256), 0, stream, logits, ld, row_max, row_lsum, alive, V, out);
     OVC_RETURN_IF_LAUNCH_FAILED();
     return OVC_OK;
 }

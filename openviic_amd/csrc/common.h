@@ -11,6 +11,7 @@
         if (hipGetLastError() != hipSuccess) return OVC_ELAUNCH; \
     } while (0)
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -27,6 +28,56 @@ __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
     return v;
+}
+// ---- reductions over the 32 lanes of one half of a wave (all 32 lanes receive the result) --------------------------------
+// four DPP steps (quad_perm xor 1, xor 2, row_half_mirror, row_mirror: full-rate VALU, no LDS) + one xor-16 exchange
+template <int CTRL>
+__device__ __forceinline__ float ovc_dpp(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+// the gfx950 row exchanges v_permlane16_swap / v_permlane32_swap: x, y = the two rows (16 lanes) / halves (32 lanes) a lane
+// pairs with, no LDS (tools/wave_reduce_probe.hip: a wave all-reduce in 116 ns against 211 ns for the ds_bpermute butterfly;
+// the empty asm statements keep hipcc from folding the two results of a swap whose inputs are the same value)
+template <bool kRows32>
+__device__ __forceinline__ void ovc_swap_rows(float v, float& x, float& y) {
+    int a = __builtin_bit_cast(int, v), c = a;
+    asm volatile("" : "+v"(c));
+    int x0, x1;
+    if (kRows32) { auto r = __builtin_amdgcn_permlane32_swap(a, c, false, false); x0 = r[0]; x1 = r[1]; }
+    else { auto r = __builtin_amdgcn_permlane16_swap(a, c, false, false); x0 = r[0]; x1 = r[1]; }
+    asm volatile("" : "+v"(x0), "+v"(x1));
+    x = __builtin_bit_cast(float, x0); y = __builtin_bit_cast(float, x1);
+}
+__device__ __forceinline__ float half_wave_max(float v) {
+    v = fmaxf(v, ovc_dpp<0xB1>(v));
+    v = fmaxf(v, ovc_dpp<0x4E>(v));
+    v = fmaxf(v, ovc_dpp<0x141>(v));
+    v = fmaxf(v, ovc_dpp<0x140>(v));
+    float x, y;
+    ovc_swap_rows<false>(v, x, y);
+    return fmaxf(x, y);
+}
+__device__ __forceinline__ float half_wave_sum(float v) {      // a fixed association order: the same bits on every tiling
+    v += ovc_dpp<0xB1>(v);
+    v += ovc_dpp<0x4E>(v);
+    v += ovc_dpp<0x141>(v);
+    v += ovc_dpp<0x140>(v);
+    float x, y;
+    ovc_swap_rows<false>(v, x, y);
+    return x + y;
+}
+// all 64 lanes
+__device__ __forceinline__ float wave_max_dpp(float v) {
+    v = half_wave_max(v);
+    float x, y;
+    ovc_swap_rows<true>(v, x, y);
+    return fmaxf(x, y);
+}
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+    v = half_wave_sum(v);
+    float x, y;
+    ovc_swap_rows<true>(v, x, y);
+    return x + y;
 }
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
@@ -62,6 +113,9 @@ struct GemmArgs {
     int kchains;         // K-order class (gemm.hip): 1 (or 0) = one summation chain over k, 4 = four interleaved chains
                          // summed in chain order.  Part of the product's DEFINITION: every tiling of a class gives the
                          // same bits, so the caller fixes it per call site and no timing can change a result.
+    float* stats;        // optional (nseg == 1, no K split): per (row, 32-column block) the block's maximum and
+    int stats_ld;        // sum exp(y - maximum) of the finished outputs, [M][stats_ld >= ceil(seg_n / 32)] float2 -- the
+                         // vocabulary projection's log-softmax pieces, so that the beam update never reads all logits back
     int objective;       // which tuning table to consult: 0 / 1 = measured in isolation, c > 1 = measured with c co-running copies
                          // (speed only: every tiling of the class gives the same bits)
     GemmSegment seg[OVC_MAX_SEGMENTS];
@@ -144,7 +198,8 @@ int ovc_beam_select_launch(const BeamSelectArgs& p, int B, hipStream_t stream);
 struct BeamUpdateArgs {
     const float* cand_v; const int* cand_i;         // [B*width, k] row candidates of ovc_beam_select_launch
     const float* logits; int ld;
-    const float* row_max; const float* row_lsum;
+    const float* row_max; const float* row_lsum;    // two-pass path: the selection kernel's log-softmax pieces per row
+    float* row_max_out; float* row_lsum_out;        // fused path: where the pieces are published (return_probs), or nullptr
     const float* alive_in; float* alive_out; float* running_out;
     const int32_t* hist_in; int32_t* hist_out;      // [B*k, T] words
     const float* lp_in; float* lp_out;              // [B*k, T] per-token log-probs
@@ -156,6 +211,12 @@ struct BeamUpdateArgs {
     const float* word_emb; const float* pos_emb; float* next_x; uint8_t* next_padflag; int d_model, pad;
 };
 int ovc_beam_update_launch(const BeamUpdateArgs& p, int B, hipStream_t stream);
+// Selection + update in one launch from the vocabulary GEMM's block pieces (GemmArgs::stats, [rows][stats_ld] float2,
+// stats_ld even): no pass over the logits.  nblk = ceil(V / 32) <= 512; p.cand_* / p.row_max / p.row_lsum are not used.
+int ovc_beam_fused_update_launch(const BeamUpdateArgs& p, const float* stats, int nblk, int stats_ld, const float* running_in,
+                                 int B, hipStream_t stream);
+int ovc_masked_logp_launch(const float* logits, int ld, const float* row_max, const float* row_lsum, const float* alive, int rows, int V,
+                           float* out, hipStream_t stream);
 
 struct BeamFinalArgs {
     const float* running; const int32_t* hist; const float* lp;

@@ -105,6 +105,7 @@ struct Workspace {
     float* kc; float* vc;                         // [L][T][R][h*dk|h*dv]
     uint8_t* padflag;                             // [T][R]
     float* logits;                                // [R][V]
+    float* stats;                                 // [R][blocks of 32 words, padded to even] float2: block maxima / sums of exponentials
     float* running[2]; float* alive[2]; int32_t* hist[2]; float* lp[2]; int32_t* anc[2];
     int32_t* tok; float* cand_v; int32_t* cand_i; float* row_max; float* row_lsum; int32_t* order;
     float* all_buf;
@@ -166,6 +167,7 @@ Workspace carve(const ovc_model* m, void* base, int B, int N, int k, int return_
     w.vc = a.take<float>(L * T * R * hv);
     w.padflag = a.take<uint8_t>(T * R);
     w.logits = a.take<float>(R * (((size_t)m->vocab + 3) & ~(size_t)3));      // rows padded to 16 bytes
+    w.stats = a.take<float>(2 * ((((size_t)m->vocab + 31) / 32 + 1) & ~(size_t)1) * R);
     for (int i = 0; i < 2; ++i) {
         w.running[i] = a.take<float>(R); w.alive[i] = a.take<float>(R);
         w.hist[i] = a.take<int32_t>(R * T); w.lp[i] = a.take<float>(R * T); w.anc[i] = a.take<int32_t>(R * T);
@@ -527,19 +529,19 @@ int run_decode_step(Engine& e, Workspace& w, int B, int N, int k, int t, int ret
     // ---- vocabulary projection, fused log-softmax + candidate scores + top-k, bookkeeping ---------
     e.gemm_class = 3;
     const int ldv = (m->vocab + 3) & ~3;            // 16-byte aligned logit rows: vector loads in the selection kernel
+    // Fused selection (round 3): the GEMM epilogue leaves per (row, 32-column block) the maximum and the sum of exponentials,
+    // and ONE kernel per image selects and updates from those pieces.  Vocabularies beyond 16 384 words (more than 512 blocks)
+    // and OVC_SELECT_TWO_PASS (A/B switch) take the round-2 pair of kernels that read every logit back.
+    const int nblk = (m->vocab + 31) / 32;
+    static const bool two_pass = getenv("OVC_SELECT_TWO_PASS") != nullptr;
+    const bool fused_select = !two_pass && nblk <= 512;
     {
         GemmArgs g{};
         g.A1 = x; g.lda1 = d; g.K1 = d; g.M = rows; g.seg_n = m->vocab; g.nseg = 1; g.ldc = ldv;
         g.seg[0] = GemmSegment{m->fc, nullptr, w.logits, nullptr, m->precision > 0 ? m->fc_planes : nullptr};
+        g.stats = fused_select ? w.stats : nullptr; g.stats_ld = (nblk + 1) & ~1;
         TRY(e.gemm(g));
     }
-    BeamSelectArgs bs{};
-    bs.logits = w.logits; bs.ld = ldv; bs.is_logp = 0;
-    bs.running = w.running[cur]; bs.alive = w.alive[cur]; bs.width = width; bs.V = m->vocab; bs.k = k;
-    bs.cand_v = w.cand_v; bs.cand_i = w.cand_i; bs.chosen = nullptr; bs.score = nullptr;   // merged by the update kernel
-    bs.masked_logp = return_probs ? w.all_buf + (size_t)t * R * m->vocab : nullptr;
-    bs.row_max_out = w.row_max; bs.row_lsum_out = w.row_lsum;
-    RUN(ovc_beam_select_launch(bs, B, s));
     BeamUpdateArgs bu{};
     bu.cand_v = w.cand_v; bu.cand_i = w.cand_i; bu.logits = w.logits; bu.ld = ldv;
     bu.row_max = w.row_max; bu.row_lsum = w.row_lsum;
@@ -551,6 +553,22 @@ int run_decode_step(Engine& e, Workspace& w, int B, int N, int k, int t, int ret
         bu.word_emb = m->word_emb; bu.pos_emb = m->pos_emb; bu.next_x = w.x; bu.next_padflag = w.padflag + (size_t)(t + 1) * R;
         bu.d_model = d; bu.pad = m->pad_idx;
     }
+    if (fused_select) {
+        // selection + bookkeeping in one launch, from the block pieces the vocabulary GEMM's epilogue left: no pass over the logits
+        bu.row_max_out = return_probs ? w.row_max : nullptr; bu.row_lsum_out = return_probs ? w.row_lsum : nullptr;
+        RUN(ovc_beam_fused_update_launch(bu, w.stats, nblk, (nblk + 1) & ~1, w.running[cur], B, s));
+        if (return_probs)     // beam_search.py:68-72: every word's masked log-probability, from the pieces the decisions used
+            RUN(ovc_masked_logp_launch(w.logits, ldv, w.row_max, w.row_lsum, w.alive[cur], rows, m->vocab,
+                                       w.all_buf + (size_t)t * R * m->vocab, s));
+        return OVC_OK;
+    }
+    BeamSelectArgs bs{};
+    bs.logits = w.logits; bs.ld = ldv; bs.is_logp = 0;
+    bs.running = w.running[cur]; bs.alive = w.alive[cur]; bs.width = width; bs.V = m->vocab; bs.k = k;
+    bs.cand_v = w.cand_v; bs.cand_i = w.cand_i; bs.chosen = nullptr; bs.score = nullptr;   // merged by the update kernel
+    bs.masked_logp = return_probs ? w.all_buf + (size_t)t * R * m->vocab : nullptr;
+    bs.row_max_out = w.row_max; bs.row_lsum_out = w.row_lsum;
+    RUN(ovc_beam_select_launch(bs, B, s));
     RUN(ovc_beam_update_launch(bu, B, s));
     return OVC_OK;
 }

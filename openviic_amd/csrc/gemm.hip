@@ -172,6 +172,25 @@ __device__ __forceinline__ void store_wave_tiles(const GemmArgs& p, int seg, con
 #pragma unroll
             for (int r = 0; r < 16; ++r)
                 __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, out[r]), rsrc_c, voff_c, ((r & 3) + 8 * (r >> 2)) * p.ldc * 4, 0);
+            if (p.stats) {
+                // Log-softmax pieces of this 32 x 32 tile (vocabulary projection): a register holds one output row per lane
+                // half with the 32 columns on the lanes, so the row's block maximum and sum exp(y - maximum) are two
+                // half-wave reductions per register.  Blocks are the global 32-column blocks (n0 is a multiple of 32) and
+                // the reduction order is fixed, so every tiling of the class leaves the same bits.  Lane l < 16 of each half
+                // then keeps register l's pair and ONE store instruction writes the tile's 32 (row, block) entries of the
+                // row-major table (8 bytes each: the reader, one workgroup per image, then streams whole rows).
+                float bm = 0.f, bs = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float v = n_ok ? out[r] : -INFINITY;
+                    const float m = half_wave_max(v);
+                    const float sum = half_wave_sum(__expf(v - m));
+                    if ((lane & 15) == r) { bm = m; bs = sum; }
+                }
+                const int rr = lane & 15, row = mbase + (rr & 3) + 8 * (rr >> 2);
+                if ((lane & 31) < 16 && row < p.M && n0 + j * 32 < p.seg_n)
+                    *reinterpret_cast<f32x2*>(p.stats + 2 * ((size_t)row * p.stats_ld + ((n0 + j * 32) >> 5))) = f32x2{bm, bs};
+            }
         }
     }
 }
@@ -633,6 +652,7 @@ int ovc_gemm_launch(const GemmArgs& a, hipStream_t stream, const GemmLaunchOpts&
         for (int s = 0; s < a.nseg; ++s)
             if (!a.seg[s].A2) return OVC_EINVAL;
     if (a.R && a.nseg != 1) return OVC_EINVAL;
+    if (a.stats && (a.nseg != 1 || a.ksplit > 1 || !ovc_aligned16(a.stats) || a.stats_ld < (a.seg_n + 31) / 32)) return OVC_EINVAL;
     if (a.K2 > 0 && (a.K1 % 32)) return OVC_EINVAL;      // the A1|A2 seam must fall on a K-tile boundary
     if (a.ksplit > 1) {                                  // raw partial products: see GemmArgs::ksplit
         if (a.ksplit > kMaxKSplit || a.nseg != 1 || a.K2 || a.R || a.act || a.seg[0].bias) return OVC_EINVAL;
