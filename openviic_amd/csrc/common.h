@@ -113,6 +113,9 @@ struct GemmArgs {
     int kchains;         // K-order class (gemm.hip): 1 (or 0) = one summation chain over k, 4 = four interleaved chains
                          // summed in chain order.  Part of the product's DEFINITION: every tiling of a class gives the
                          // same bits, so the caller fixes it per call site and no timing can change a result.
+    uint8_t* zero_rows_out;  // optional (fp32 classes, K2 == 0, no K split): zero_rows_out[m] = (sum_k A1[m, k] == 0), the padding
+                         // mask of models/utils.py:48-61, found by the workgroups of the first column tile while they stage A --
+                         // the feature projection then is the only pass over the caller's features
     float* stats;        // optional (nseg == 1, no K split): per (row, 32-column block) the block's maximum and
     int stats_ld;        // sum exp(y - maximum) of the finished outputs, [M][stats_ld >= ceil(seg_n / 32)] float2 -- the
                          // vocabulary projection's log-softmax pieces, so that the beam update never reads all logits back

@@ -199,6 +199,14 @@ __global__ __launch_bounds__(256) void decode_embed_kernel(const int32_t* __rest
     for (int c = lane; c < (d >> 2); c += 64) o[c] = e[c] + p[c];
 }
 
+// Measurement hook (OVC_DEBUG_SKIP=mask): leave out classes of decode-step launches to see what each costs with several
+// batches in flight (results are garbage; timing only).  1 = AddNorm LayerNorms, 2 = self-attention, 4 = cross-attention,
+// 8 = the vocabulary projection's selection / update.  Never set in production.
+int debug_skip() {
+    static const int mask = [] { const char* e = getenv("OVC_DEBUG_SKIP"); return e ? atoi(e) : 0; }();
+    return mask;
+}
+
 // Measurement hook (OVC_DEBUG_EXTRA_LAUNCHES=n): n empty launches behind every AddNorm LayerNorm of the decode step -- how much
 // does a kernel BOUNDARY cost the whole chip when several streams are in flight?  Never set in production.
 __global__ void noop_kernel() {}
@@ -317,7 +325,8 @@ struct Engine {
         a.seg[0] = seg(l, part); a.seg[0].bias = nullptr;     // raw partial products: bias applied by the consumer
         TRY(gemm(a));
         if (dry) return OVC_OK;
-        TRY(ovc_layer_norm_parts(part, split, a.part_stride, l.b, residual, ln.g, ln.b, zero_rows, m->ln_eps, out, M, d, stream));
+        if (!(debug_skip() & 1))
+            TRY(ovc_layer_norm_parts(part, split, a.part_stride, l.b, residual, ln.g, ln.b, zero_rows, m->ln_eps, out, M, d, stream));
         for (int i = 0; i < extra_launches(); ++i) hipLaunchKernelGGL(noop_kernel, dim3(1), dim3(64), 0, stream);
         return OVC_OK;
     }
@@ -358,8 +367,17 @@ int run_encoder_inputs(Engine& e, Workspace& w, const float* features, const flo
     if (!e.dry && m->enc_kind == OVC_ENC_GEOMETRIC && (!boxes || !m->fc_g_w || !m->fc_g_b)) return OVC_EINVAL;
     e.gemm_class = 0;
     e.kchains = 1;            // M = B*N products: one summation chain (gemm.hip, K-order classes)
-    RUN(ovc_zero_row_mask(features, BN, m->d_feat, w.enc_mask, s));
-    TRY(e.linear(features, m->d_feat, m->proj, nullptr, w.ey, BN, d, 0));
+    // K1 (models/utils.py:48-61): the padding mask is the row sum of the features.  In the fp32 mode the feature projection
+    // finds it while it stages its A tiles (GemmArgs::zero_rows_out): one pass over the caller's 105 MB instead of two.
+    {
+        GemmArgs a{};
+        a.A1 = features; a.lda1 = m->d_feat; a.K1 = m->d_feat; a.M = BN; a.seg_n = d; a.nseg = 1; a.ldc = d;
+        a.seg[0] = e.seg(m->proj, w.ey);
+        static const bool separate = getenv("OVC_K1_SEPARATE") != nullptr;        // A/B switch: the round-1 mask kernel
+        if (m->precision == 0 && !separate) a.zero_rows_out = w.enc_mask;
+        else RUN(ovc_zero_row_mask(features, BN, m->d_feat, w.enc_mask, s));
+        TRY(e.gemm(a));
+    }
     if (m->enc_kind == OVC_ENC_GEOMETRIC)
         RUN(ovc_box_relation_weights(boxes, B, N, m->fc_g_w, m->fc_g_b, m->heads, m->d_g, m->trig, w.geometry, s));
     return OVC_OK;
@@ -466,7 +484,7 @@ int run_decode_step(Engine& e, Workspace& w, int B, int N, int k, int t, int ret
         sa.q = w.q; sa.ldq = hk; sa.kcache = kc; sa.vcache = vc; sa.pos_stride = (size_t)R * hk; sa.ldkv = hk;
         sa.anc = w.anc[cur]; sa.anc_ld = T; sa.padflag = w.padflag; sa.pad_ld = R; sa.t = t; sa.width = width;
         sa.h = m->heads; sa.dk = m->d_k; sa.dv = m->d_v; sa.out = w.att; sa.ldo = hv;
-        RUN(ovc_decode_self_attention(sa, rows, s));
+        if (!(debug_skip() & 2)) RUN(ovc_decode_self_attention(sa, rows, s));
         TRY(e.linear_ln(w.att, hv, dl.self_att.o, x, dl.self_att.ln, nullptr, w.y, w.part, w.x1, rows));
         TRY(e.aoa(dl.self_att, x, w.x1, w.info, w.gate, rows));
 
@@ -477,7 +495,7 @@ int run_decode_step(Engine& e, Workspace& w, int B, int N, int k, int t, int ret
         ca.kx = w.kx + (size_t)l * lv * B * N * hk; ca.vx = w.vx + (size_t)l * lv * B * N * hv;
         ca.level_stride = (size_t)B * N * hk; ca.ldkv = hk; ca.encmask = w.enc_mask; ca.n = N; ca.width = width;
         ca.heads = m->heads; ca.dk = m->d_k; ca.dv = m->d_v; ca.out = w.att; ca.out_level_stride = (size_t)rows * hv; ca.ldo = hv;
-        RUN(ovc_decode_cross_attention(ca, B, m->heads, lv, s));
+        if (!(debug_skip() & 4)) RUN(ovc_decode_cross_attention(ca, B, m->heads, lv, s));
         float* ffn_in;
         if (m->dec_kind == OVC_DEC_MESHED) {
             // decoders.py:51-73: one shared enc_attn per level, sigmoid-gated sum / sqrt(levels).  The levels'
@@ -556,7 +574,7 @@ int run_decode_step(Engine& e, Workspace& w, int B, int N, int k, int t, int ret
     if (fused_select) {
         // selection + bookkeeping in one launch, from the block pieces the vocabulary GEMM's epilogue left: no pass over the logits
         bu.row_max_out = return_probs ? w.row_max : nullptr; bu.row_lsum_out = return_probs ? w.row_lsum : nullptr;
-        RUN(ovc_beam_fused_update_launch(bu, w.stats, nblk, (nblk + 1) & ~1, w.running[cur], B, s));
+        if (!(debug_skip() & 8)) RUN(ovc_beam_fused_update_launch(bu, w.stats, nblk, (nblk + 1) & ~1, w.running[cur], B, s));
         if (return_probs)     // beam_search.py:68-72: every word's masked log-probability, from the pieces the decisions used
             RUN(ovc_masked_logp_launch(w.logits, ldv, w.row_max, w.row_lsum, w.alive[cur], rows, m->vocab,
                                        w.all_buf + (size_t)t * R * m->vocab, s));

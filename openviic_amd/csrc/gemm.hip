@@ -287,6 +287,11 @@ __global__ __launch_bounds__(256, (min_waves_per_simd<BM, BN, BK, NC>())) void g
     };
     // The loaded registers are first touched here, after the MFMA block of the previous tile, so the
     // global-load latency hides under the matrix work (issue early / write late).
+    // K1 fold (GemmArgs::zero_rows_out): the workgroups of the first column tile add up the A rows they stage anyway
+    const bool row_sums = p.zero_rows_out != nullptr && tile_n_all == 0;      // uniform
+    float rs[Cfg::kLoadA];
+#pragma unroll
+    for (int i = 0; i < Cfg::kLoadA; ++i) rs[i] = 0.f;
     auto store_tile = [&](int buf) {
         const int kq = tid % kVecPerRow;
         if (k_tail) {
@@ -296,6 +301,10 @@ __global__ __launch_bounds__(256, (min_waves_per_simd<BM, BN, BK, NC>())) void g
 #pragma unroll
             for (int i = 0; i < Cfg::kLoadB; ++i)
                 if (!w_ok) stage_b[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        if (row_sums) {
+#pragma unroll
+            for (int i = 0; i < Cfg::kLoadA; ++i) rs[i] += (stage_a[i][0] + stage_a[i][1]) + (stage_a[i][2] + stage_a[i][3]);
         }
 #pragma unroll
         for (int i = 0; i < Cfg::kLoadA; ++i) {
@@ -366,6 +375,18 @@ __global__ __launch_bounds__(256, (min_waves_per_simd<BM, BN, BK, NC>())) void g
             store_tile(Cfg::kBufs == 2 ? (buf ^ 1) : 0);
         }
         __syncthreads();
+    }
+
+    if (row_sums) {
+        // the kVecPerRow consecutive lanes that staged one row hold its partial sums: butterfly inside that group
+#pragma unroll
+        for (int i = 0; i < Cfg::kLoadA; ++i) {
+            float v = rs[i];
+#pragma unroll
+            for (int off = 1; off < kVecPerRow; off <<= 1) v += __shfl_xor(v, off, 64);
+            const int row = m0 + tid / kVecPerRow + i * kRowsPerPass;
+            if (tid % kVecPerRow == 0 && row < p.M) p.zero_rows_out[row] = (v == 0.f) ? 1 : 0;
+        }
     }
 
     // Chain reduction, always in chain order ((c0 + c1) + c2) + c3 whatever the wave layout: chain c lives in wave
@@ -652,6 +673,7 @@ int ovc_gemm_launch(const GemmArgs& a, hipStream_t stream, const GemmLaunchOpts&
         for (int s = 0; s < a.nseg; ++s)
             if (!a.seg[s].A2) return OVC_EINVAL;
     if (a.R && a.nseg != 1) return OVC_EINVAL;
+    if (a.zero_rows_out && (a.K2 || a.ksplit > 1 || a.kchains > kSplitClass)) return OVC_EINVAL;
     if (a.stats && (a.nseg != 1 || a.ksplit > 1 || !ovc_aligned16(a.stats) || a.stats_ld < (a.seg_n + 31) / 32)) return OVC_EINVAL;
     if (a.K2 > 0 && (a.K1 % 32)) return OVC_EINVAL;      // the A1|A2 seam must fall on a K-tile boundary
     if (a.ksplit > 1) {                                  // raw partial products: see GemmArgs::ksplit
