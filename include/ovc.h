@@ -271,7 +271,9 @@ const char* ovc_profile_kernel_name(int tiling);   /* "" past the last tiling */
  * that shape and class use it, and shapes whose M is within a factor of two of a measured one borrow its entry.
  * scratch: >= 4*(M*K + nseg*seg_n*K + ksplit*M*nseg*seg_n) + 64 bytes of device memory (contents are used as
  * operands); for the split-precision classes, nseg * ovc_split_weight_bytes(seg_n, K, kchains - 100) more bytes make the
- * measurement use pre-cut weight planes (what the engine runs when ovc_lin::planes are set).
+ * measurement use pre-cut weight planes (what the engine runs when ovc_lin::planes are set); a single-segment
+ * kchains = 4 product with seg_n >= 4096 (the engine's vocabulary projection) is measured with its log-softmax epilogue
+ * when 8 * M * (seg_n / 32 + 4) more bytes are there.
  * `objective` (1..8) = what is minimised: the time of that many identical products co-running in one launch.  1 ranks
  * tilings by isolated latency, which favours many small tiles; with several independent batches in flight on different
  * streams, rank with objective = that number: fewer, larger tiles then win because they spend fewer CU-seconds and less

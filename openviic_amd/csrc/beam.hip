@@ -430,7 +430,8 @@ constexpr int kHotCap = 512, kFusedSurvCap = 1024, kFusedThreads = 512, kFusedPa
 // 512 threads per image: wave w < width owns beam row w through phases A and B (no workgroup-level reduction), then all
 // eight waves gather the hot blocks and wave 0 ranks the survivors in registers.
 __global__ __launch_bounds__(kFusedThreads) void beam_fused_update_kernel(BeamUpdateArgs p, const float* __restrict__ stats, int nblk,
-                                                                          int stats_ld, const float* __restrict__ running_in) {
+                                                                          int stats_ld, const float* __restrict__ running_in,
+                                                                          long ld_row, long ld_word) {
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int W = p.width, k = p.k, V = p.V, T = p.T, t = p.t;
     __shared__ float rowM[kMaxK], rowLs[kMaxK], rowRun[kMaxK], thr[kMaxK];
@@ -526,7 +527,7 @@ __global__ __launch_bounds__(kFusedThreads) void beam_fused_update_kernel(BeamUp
                 const int h = min(h0 + u * kPerPass + (tid >> 5), H - 1);
                 ri[u] = hot_row[h];
                 col[u] = min(hot_blk[h] * 32 + (tid & 31), V - 1);
-                x[u] = p.logits[((size_t)b * W + ri[u]) * p.ld + col[u]];
+                x[u] = p.logits[(size_t)(b * W + ri[u]) * ld_row + (size_t)col[u] * ld_word];
             }
 #pragma unroll
             for (int u = 0; u < kPasses; ++u) {
@@ -577,11 +578,11 @@ __global__ __launch_bounds__(kFusedThreads) void beam_fused_update_kernel(BeamUp
             Cand c; c.v = -INFINITY; c.idx = 0x7fffffff;
             float cx = 0.f;
             for (int i = 0; i < W; ++i) {
-                const float* x = p.logits + ((size_t)b * W + i) * p.ld;
+                const float* x = p.logits + (size_t)(b * W + i) * ld_row;
                 const float ri = rowRun[i], mi = rowM[i], li = rowLs[i];
                 const bool alive_i = rowLive[i] != 0;
                 for (int col = tid; col < V; col += kFusedThreads) {
-                    const float xc = x[col];
+                    const float xc = x[(size_t)col * ld_word];
                     const float cand = alive_i ? ri + ((xc - mi) - li) : (col == 0 ? ri : -999.0f);
                     const int idx = i * V + col;
                     const bool after = cand < pv || (cand == pv && idx > pi);
@@ -611,7 +612,8 @@ __global__ __launch_bounds__(kFusedThreads) void beam_fused_update_kernel(BeamUp
         const float alive = rowLive[par] ? p.alive_in[b * W + par] : 0.0f;
         // the carried logit is the winner's own; without a winner, or for a frozen beam's fixed candidates (whose product with
         // alive = 0 only needs a finite operand), the logit is read as the two-pass path reads it
-        const float x = ((unsigned)win_i[tid] < (unsigned)(W * V) && rowLive[par]) ? win_x[tid] : p.logits[((size_t)b * W + par) * p.ld + wd];
+        const float x = ((unsigned)win_i[tid] < (unsigned)(W * V) && rowLive[par]) ? win_x[tid]
+                                                                                   : p.logits[(size_t)(b * W + par) * ld_row + (size_t)wd * ld_word];
         const float lp = ((x - rowM[par]) - rowLs[par]) * alive;
         p.running_out[b * k + tid] = win_v[tid];
         p.alive_out[b * k + tid] = alive * (wd != p.eos ? 1.0f : 0.0f);
@@ -626,14 +628,14 @@ __global__ __launch_bounds__(kFusedThreads) void beam_fused_update_kernel(BeamUp
 
 // masked_logp[row, c] = ((x - row_max) - row_lsum) * alive for every word (return_probs; beam_search.py:68-72) from the
 // row pieces beam_fused_update_kernel published -- the values its decisions were taken on.
-__global__ __launch_bounds__(256) void masked_logp_kernel(const float* __restrict__ logits, int ld, const float* __restrict__ row_max,
-                                                          const float* __restrict__ row_lsum, const float* __restrict__ alive, int V,
-                                                          float* __restrict__ out) {
+__global__ __launch_bounds__(256) void masked_logp_kernel(const float* __restrict__ logits, long ld_row, long ld_word,
+                                                          const float* __restrict__ row_max, const float* __restrict__ row_lsum,
+                                                          const float* __restrict__ alive, int V, float* __restrict__ out) {
     const int row = blockIdx.x;
     const float m = row_max[row], l = row_lsum[row], a = alive ? alive[row] : 1.0f;
-    const float* x = logits + (size_t)row * ld;
+    const float* x = logits + (size_t)row * ld_row;
     float* y = out + (size_t)row * V;
-    for (int c = threadIdx.x; c < V; c += 256) y[c] = ((x[c] - m) - l) * a;
+    for (int c = threadIdx.x; c < V; c += 256) y[c] = ((x[(size_t)c * ld_word] - m) - l) * a;
 }
 
 // Final ordering (beam_search.py:97-113): beams sorted by total score, descending, stable.
@@ -714,18 +716,19 @@ int ovc_beam_update_launch(const BeamUpdateArgs& p, int B, hipStream_t stream) {
 }
 
 int ovc_beam_fused_update_launch(const BeamUpdateArgs& p, const float* stats, int nblk, int stats_ld, const float* running_in,
-                                 int B, hipStream_t stream) {
+                                 long ld_row, long ld_word, int B, hipStream_t stream) {
     if (B <= 0 || p.width <= 0 || p.width > kMaxK || p.k <= 0 || p.k > kMaxK || p.V <= 0 || !stats || !running_in) return OVC_EINVAL;
     if (nblk != (p.V + 31) / 32 || nblk > 512 || stats_ld < nblk || (stats_ld & 1) || !ovc_aligned16(stats)) return OVC_EINVAL;
     if ((long)p.width * p.V < p.k) return OVC_EINVAL;
-    hipLaunchKernelGGL(beam_fused_update_kernel, dim3(B), dim3(kFusedThreads), 0, stream, p, stats, nblk, stats_ld, running_in);
+    if (ld_row <= 0 || ld_word <= 0) return OVC_EINVAL;
+    hipLaunchKernelGGL(beam_fused_update_kernel, dim3(B), dim3(kFusedThreads), 0, stream, p, stats, nblk, stats_ld, running_in, ld_row, ld_word);
     OVC_RETURN_IF_LAUNCH_FAILED();
     return OVC_OK;
 }
 
-int ovc_masked_logp_launch(const float* logits, int ld, const float* row_max, const float* row_lsum, const float* alive, int rows, int V,
-                           float* out, hipStream_t stream) {
-    hipLaunchKernelGGL(masked_logp_kernel, dim3(rows), dim3(256), 0, stream, logits, ld, row_max, row_lsum, alive, V, out);
+int ovc_masked_logp_launch(const float* logits, long ld_row, long ld_word, const float* row_max, const float* row_lsum,
+                           const float* alive, int rows, int V, float* out, hipStream_t stream) {
+    hipLaunchKernelGGL(masked_logp_kernel, dim3(rows), dim3(256), 0, stream, logits, ld_row, ld_word, row_max, row_lsum, alive, V, out);
     OVC_RETURN_IF_LAUNCH_FAILED();
     return OVC_OK;
 }

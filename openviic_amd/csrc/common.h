@@ -119,6 +119,9 @@ struct GemmArgs {
     float* stats;        // optional (nseg == 1, no K split): per (row, 32-column block) the block's maximum and
     int stats_ld;        // sum exp(y - maximum) of the finished outputs, [M][stats_ld >= ceil(seg_n / 32)] float2 -- the
                          // vocabulary projection's log-softmax pieces, so that the beam update never reads all logits back
+    float* stats_t;      // the same pieces for a TRANSPOSED product (rows of C are the words, columns the beam rows): per (column n,
+                         // 32-row block) the maximum and sum exp over the block's rows, [seg_n][stats_ld] float2.  A lane of the
+                         // accumulator then holds 16 words of ONE beam row, so the reductions are in-register (one half-wave swap each)
     int objective;       // which tuning table to consult: 0 / 1 = measured in isolation, c > 1 = measured with c co-running copies
                          // (speed only: every tiling of the class gives the same bits)
     GemmSegment seg[OVC_MAX_SEGMENTS];
@@ -216,10 +219,12 @@ struct BeamUpdateArgs {
 int ovc_beam_update_launch(const BeamUpdateArgs& p, int B, hipStream_t stream);
 // Selection + update in one launch from the vocabulary GEMM's block pieces (GemmArgs::stats, [rows][stats_ld] float2,
 // stats_ld even): no pass over the logits.  nblk = ceil(V / 32) <= 512; p.cand_* / p.row_max / p.row_lsum are not used.
+// Logit (row, word) lives at logits[row * ld_row + word * ld_word]: (ld, 1) for the row-major product, (1, ld) for the
+// transposed one.
 int ovc_beam_fused_update_launch(const BeamUpdateArgs& p, const float* stats, int nblk, int stats_ld, const float* running_in,
-                                 int B, hipStream_t stream);
-int ovc_masked_logp_launch(const float* logits, int ld, const float* row_max, const float* row_lsum, const float* alive, int rows, int V,
-                           float* out, hipStream_t stream);
+                                 long ld_row, long ld_word, int B, hipStream_t stream);
+int ovc_masked_logp_launch(const float* logits, long ld_row, long ld_word, const float* row_max, const float* row_lsum,
+                           const float* alive, int rows, int V, float* out, hipStream_t stream);
 
 struct BeamFinalArgs {
     const float* running; const int32_t* hist; const float* lp;

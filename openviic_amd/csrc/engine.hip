@@ -166,7 +166,7 @@ Workspace carve(const ovc_model* m, void* base, int B, int N, int k, int return_
     w.kc = a.take<float>(L * T * R * hk);
     w.vc = a.take<float>(L * T * R * hv);
     w.padflag = a.take<uint8_t>(T * R);
-    w.logits = a.take<float>(R * (((size_t)m->vocab + 3) & ~(size_t)3));      // rows padded to 16 bytes
+    w.logits = a.take<float>(((R + 3) & ~(size_t)3) * (((size_t)m->vocab + 3) & ~(size_t)3));   // [R][V] or [V][R], rows padded to 16 bytes
     w.stats = a.take<float>(2 * ((((size_t)m->vocab + 31) / 32 + 1) & ~(size_t)1) * R);
     for (int i = 0; i < 2; ++i) {
         w.running[i] = a.take<float>(R); w.alive[i] = a.take<float>(R);
@@ -553,13 +553,29 @@ int run_decode_step(Engine& e, Workspace& w, int B, int N, int k, int t, int ret
     const int nblk = (m->vocab + 31) / 32;
     static const bool two_pass = getenv("OVC_SELECT_TWO_PASS") != nullptr;
     const bool fused_select = !two_pass && nblk <= 512;
+    // fp32 mode + fused selection: the product runs TRANSPOSED -- logits^T [V][rows] = fc [V, d] . x^T, the same kernel with the
+    // operands' roles swapped (both are K-contiguous) and the same bits (every dot product sums the same k order; a * b
+    // commutes).  A lane of the accumulator then holds 16 WORDS of one beam row, which makes the block maximum / sum exp an
+    // in-register reduction (~70 vector instructions per tile instead of ~370 across lanes), and a store instruction still
+    // writes whole 128-byte lines (32 consecutive beam rows of one word).  The split-precision modes keep the row-major
+    // product: their pre-cut weight planes are B-operand planes.
+    static const bool row_major = getenv("OVC_VOCAB_ROW_MAJOR") != nullptr;        // A/B switch
+    const bool transposed = fused_select && m->precision == 0 && !row_major;
+    const int ldt = (rows + 3) & ~3;               // row stride of logits^T
     {
         GemmArgs g{};
-        g.A1 = x; g.lda1 = d; g.K1 = d; g.M = rows; g.seg_n = m->vocab; g.nseg = 1; g.ldc = ldv;
-        g.seg[0] = GemmSegment{m->fc, nullptr, w.logits, nullptr, m->precision > 0 ? m->fc_planes : nullptr};
-        g.stats = fused_select ? w.stats : nullptr; g.stats_ld = (nblk + 1) & ~1;
+        if (transposed) {
+            g.A1 = m->fc; g.lda1 = d; g.K1 = d; g.M = m->vocab; g.seg_n = rows; g.nseg = 1; g.ldc = ldt;
+            g.seg[0] = GemmSegment{x, nullptr, w.logits, nullptr, nullptr};
+            g.stats_t = w.stats; g.stats_ld = (nblk + 1) & ~1;
+        } else {
+            g.A1 = x; g.lda1 = d; g.K1 = d; g.M = rows; g.seg_n = m->vocab; g.nseg = 1; g.ldc = ldv;
+            g.seg[0] = GemmSegment{m->fc, nullptr, w.logits, nullptr, m->precision > 0 ? m->fc_planes : nullptr};
+            g.stats = fused_select ? w.stats : nullptr; g.stats_ld = (nblk + 1) & ~1;
+        }
         TRY(e.gemm(g));
     }
+    const long ld_row = transposed ? 1 : ldv, ld_word = transposed ? ldt : 1;
     BeamUpdateArgs bu{};
     bu.cand_v = w.cand_v; bu.cand_i = w.cand_i; bu.logits = w.logits; bu.ld = ldv;
     bu.row_max = w.row_max; bu.row_lsum = w.row_lsum;
@@ -574,9 +590,9 @@ int run_decode_step(Engine& e, Workspace& w, int B, int N, int k, int t, int ret
     if (fused_select) {
         // selection + bookkeeping in one launch, from the block pieces the vocabulary GEMM's epilogue left: no pass over the logits
         bu.row_max_out = return_probs ? w.row_max : nullptr; bu.row_lsum_out = return_probs ? w.row_lsum : nullptr;
-        if (!(debug_skip() & 8)) RUN(ovc_beam_fused_update_launch(bu, w.stats, nblk, (nblk + 1) & ~1, w.running[cur], B, s));
+        if (!(debug_skip() & 8)) RUN(ovc_beam_fused_update_launch(bu, w.stats, nblk, (nblk + 1) & ~1, w.running[cur], ld_row, ld_word, B, s));
         if (return_probs)     // beam_search.py:68-72: every word's masked log-probability, from the pieces the decisions used
-            RUN(ovc_masked_logp_launch(w.logits, ldv, w.row_max, w.row_lsum, w.alive[cur], rows, m->vocab,
+            RUN(ovc_masked_logp_launch(w.logits, ld_row, ld_word, w.row_max, w.row_lsum, w.alive[cur], rows, m->vocab,
                                        w.all_buf + (size_t)t * R * m->vocab, s));
         return OVC_OK;
     }

@@ -172,6 +172,31 @@ __device__ __forceinline__ void store_wave_tiles(const GemmArgs& p, int seg, con
 #pragma unroll
             for (int r = 0; r < 16; ++r)
                 __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, out[r]), rsrc_c, voff_c, ((r & 3) + 8 * (r >> 2)) * p.ldc * 4, 0);
+            if (p.stats_t) {
+                // Transposed vocabulary product: this lane's 16 registers are 16 words (rows) of ONE beam row (column n), and the
+                // lane 32 further on holds the block's other 16.  Block maximum and sum exp(y - maximum) are in-register
+                // reductions in register order plus one half-wave exchange each -- ~70 vector instructions per tile where the
+                // row-major form (below) needs ~370.  The 32-row blocks are global (m0 is a multiple of 32) and the order is
+                // fixed: every tiling leaves the same bits.
+                const int mrow = m0 + i * 32 + 4 * half;
+                float v[16];
+                float bm = -INFINITY;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    v[r] = mrow + (r & 3) + 8 * (r >> 2) < p.M ? out[r] : -INFINITY;
+                    bm = fmaxf(bm, v[r]);
+                }
+                float x, y;
+                ovc_swap_rows<true>(bm, x, y);
+                bm = fmaxf(x, y);
+                float bs = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) bs += __expf(v[r] - bm);
+                ovc_swap_rows<true>(bs, x, y);
+                bs = x + y;
+                if (lane < 32 && n_ok && m0 + i * 32 < p.M)
+                    *reinterpret_cast<f32x2*>(p.stats_t + 2 * ((size_t)n * p.stats_ld + ((m0 + i * 32) >> 5))) = f32x2{bm, bs};
+            }
             if (p.stats) {
                 // Log-softmax pieces of this 32 x 32 tile (vocabulary projection): a register holds one output row per lane
                 // half with the 32 columns on the lanes, so the row's block maximum and sum exp(y - maximum) are two
@@ -675,6 +700,7 @@ int ovc_gemm_launch(const GemmArgs& a, hipStream_t stream, const GemmLaunchOpts&
     if (a.R && a.nseg != 1) return OVC_EINVAL;
     if (a.zero_rows_out && (a.K2 || a.ksplit > 1 || a.kchains > kSplitClass)) return OVC_EINVAL;
     if (a.stats && (a.nseg != 1 || a.ksplit > 1 || !ovc_aligned16(a.stats) || a.stats_ld < (a.seg_n + 31) / 32)) return OVC_EINVAL;
+    if (a.stats_t && (a.stats || a.seg[0].bias || a.nseg != 1 || a.ksplit > 1 || !ovc_aligned16(a.stats_t) || a.stats_ld < (a.M + 31) / 32)) return OVC_EINVAL;
     if (a.K2 > 0 && (a.K1 % 32)) return OVC_EINVAL;      // the A1|A2 seam must fall on a K-tile boundary
     if (a.ksplit > 1) {                                  // raw partial products: see GemmArgs::ksplit
         if (a.ksplit > kMaxKSplit || a.nseg != 1 || a.K2 || a.R || a.act || a.seg[0].bias) return OVC_EINVAL;
@@ -730,6 +756,16 @@ extern "C" int ovc_gemm_tune(int M, int seg_n, int nseg, int K, int kchains, int
         if ((size_t)(P - A) + (size_t)nseg * plane_floats <= scratch_bytes / sizeof(float))
             for (int s = 0; s < nseg; ++s) a.seg[s].Wp = P + (size_t)s * plane_floats;
     }
+    // Wide single-segment products of the decode class (the engine has one: the vocabulary projection) run with the
+    // log-softmax epilogue (GemmArgs::stats); rank their tilings WITH it when the scratch buffer has room behind the outputs
+    // (its cost depends on the tiling's register budget: the K-tile-64 instance loses 5 us to it, the K-tile-32 one 4)
+    if (kchains == 4 && nseg == 1 && ksplit == 1 && (seg_n >= 4096 || M >= 4096)) {
+        const bool transposed = M >= 4096;                     // the fp32 engine runs the product transposed (words = rows)
+        const int ld = (((transposed ? M : seg_n) + 31) / 32 + 1) & ~1;
+        const size_t entries = (size_t)(transposed ? seg_n : M) * ld;
+        float* S = C + ((nc + 3) & ~(size_t)3);
+        if ((size_t)(S - A) + 2 * entries <= scratch_bytes / sizeof(float)) { (transposed ? a.stats_t : a.stats) = S; a.stats_ld = ld; }
+    }
     hipStream_t st = ovc_hip_stream(stream);
     hipEvent_t e0, e1;
     if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return OVC_ELAUNCH;
@@ -741,12 +777,16 @@ extern "C" int ovc_gemm_tune(int M, int seg_n, int nseg, int K, int kchains, int
         if (!tiling_fits(a, t)) continue;
         opts.forced_tiling = t;
         for (int i = 0; i < 2 && rc == OVC_OK; ++i) rc = ovc_gemm_launch(a, st, opts);
-        (void)hipEventRecord(e0, st);
-        for (int i = 0; i < 6 && rc == OVC_OK; ++i) rc = ovc_gemm_launch(a, st, opts);
-        (void)hipEventRecord(e1, st);
-        if (hipEventSynchronize(e1) != hipSuccess) rc = OVC_ELAUNCH;
-        float ms = 0.f;
-        if (rc == OVC_OK && hipEventElapsedTime(&ms, e0, e1) == hipSuccess && ms < best_ms) { best_ms = ms; best = t; }
+        // the faster of three groups of six back-to-back launches: one group alone mis-ranks tilings that are 2-3 % apart
+        // (round 3: the vocabulary product got the K-tile-64 instance on some boxes, 5 us slower than the K-tile-32 one)
+        for (int group = 0; group < 3 && rc == OVC_OK; ++group) {
+            (void)hipEventRecord(e0, st);
+            for (int i = 0; i < 6 && rc == OVC_OK; ++i) rc = ovc_gemm_launch(a, st, opts);
+            (void)hipEventRecord(e1, st);
+            if (hipEventSynchronize(e1) != hipSuccess) rc = OVC_ELAUNCH;
+            float ms = 0.f;
+            if (rc == OVC_OK && hipEventElapsedTime(&ms, e0, e1) == hipSuccess && ms < best_ms) { best_ms = ms; best = t; }
+        }
     }
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     g_tune_calls.fetch_add(1);

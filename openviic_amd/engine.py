@@ -258,7 +258,8 @@ class CaptionEngine:
         if todo:
             # operands + output (K-split shapes: one partial output per slice)
             # (+ room for pre-cut weight planes in the split-precision classes: the tuner then ranks the instances the engine runs)
-            need = max(4 * (m * kk + sn * ns * kk + m * sn * ns * ks) + 256 +
+            # (+ room for the log-softmax block pieces of a wide decode-class product: it is then ranked with that epilogue)
+            need = max(4 * (m * kk + sn * ns * kk + m * sn * ns * ks) + 256 + 8 * m * (sn // 32 + 4) +
                        (ns * self.lib.ovc_split_weight_bytes(sn, kk, kc - 100) if kc > 100 else 0) for m, sn, ns, kk, kc, ks in todo)
             scratch = torch.empty(need // 4 + 16, dtype=torch.float32, device=self.device).normal_()
             for sh in todo:
