@@ -461,12 +461,22 @@ void tile_order(const GemmArgs& a, int tiles_m, int tiles_n, int* group_m, int* 
     *group_m = a_bytes <= (size_t)3 << 20 ? tiles_m : (tiles_m < 8 ? tiles_m : 8);
     *xcd_pm = 0;
     const int slices = a.ksplit > 1 ? a.ksplit : 1;
+    const size_t w_bytes = sizeof(float) * (size_t)a.seg_n * a.nseg * (a.K1 + a.K2);
+    const int tiles_n_all = tiles_n * a.nseg;
     if (a_bytes / slices <= (size_t)3 << 20) {
-        const size_t w_bytes = sizeof(float) * (size_t)a.seg_n * a.nseg * (a.K1 + a.K2);
-        const int tiles_n_all = tiles_n * a.nseg;
         size_t best = 8 * a_bytes + w_bytes;
         for (int pm = 2; pm <= 8; pm *= 2) {
             if (tiles_m % pm || tiles_n_all % (8 / pm)) continue;
+            const size_t cost = (size_t)(8 / pm) * a_bytes + (size_t)pm * w_bytes;
+            if (cost < best) { best = cost; *xcd_pm = pm; }
+        }
+    } else if (slices == 1 && w_bytes <= (size_t)3 << 20) {
+        // A exceeds an L2 but W fits one and an XCD's share of A does (the transposed vocabulary product: A = fc, 21 MB,
+        // W = the 2.6 MB of decoder outputs): split M over the XCDs -- inside a sub-rectangle M runs fastest, so the XCD's A
+        // panel is re-used for every N tile and A is read ONCE overall: pn |A| + pm |W| = 42 MB where super-rows read 74 MB
+        size_t best = ~(size_t)0;
+        for (int pm = 8; pm >= 2; pm /= 2) {
+            if (tiles_m % pm || tiles_n_all % (8 / pm) || a_bytes / pm > (size_t)3 << 20) continue;
             const size_t cost = (size_t)(8 / pm) * a_bytes + (size_t)pm * w_bytes;
             if (cost < best) { best = cost; *xcd_pm = pm; }
         }
