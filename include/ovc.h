@@ -310,6 +310,16 @@ int ovc_debug_force_gemm_tiling(int tiling);
 int ovc_debug_linear_tiling(const float* x, int K, const float* W, const float* bias, float* y, int M, int N,
                             int tiling, int ksplit, int iters, ovc_stream stream);
 
+/* Test hook: ONE selection step of the engine's fused path on caller-supplied decoder outputs x [B*width, d] -- the
+ * vocabulary product fc [V, d] with its log-softmax epilogue (transposed != 0: logits^T = fc . x^T as the fp32 engine runs
+ * it; 0: the row-major form) and the fused select + update kernel, which never reads the logits back -- against which a
+ * stable sort can be checked at the operator level.  chosen [B, k] = flat indices beam * V + word in winning order,
+ * score [B, k]; scratch >= ovc_debug_vocab_select_bytes(B, width, V, k), 16-byte aligned.  V <= 16384. */
+size_t ovc_debug_vocab_select_bytes(int B, int width, int V, int k);
+int ovc_debug_vocab_select(const float* x, const float* fc, const float* running, const float* alive, int B, int width,
+                           int V, int d, int k, int transposed, void* scratch, size_t scratch_bytes, int64_t* chosen,
+                           float* score, ovc_stream stream);
+
 /* Split-precision modes: a weight W [N, K] (K a multiple of 16) cut ONCE into the 16-bit planes of `mode` (3 or 4, as
  * ovc_model::precision), stored in MFMA-operand order so that the GEMM's waves read them straight from memory instead of
  * cutting W again in every workgroup.  ovc_split_weight_bytes = size of `planes` (0 = invalid arguments); the planes hold the

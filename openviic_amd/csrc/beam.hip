@@ -726,6 +726,25 @@ int ovc_beam_fused_update_launch(const BeamUpdateArgs& p, const float* stats, in
     return OVC_OK;
 }
 
+namespace {
+__global__ void collect_winners_kernel(const int32_t* anc, const int32_t* word, const float* running, int n, int k, int width, int V,
+                                       int64_t* chosen, float* score) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int b = i / k;
+    chosen[i] = (int64_t)(anc[i] - b * width) * V + word[i];
+    score[i] = running[i];
+}
+}  // namespace
+
+int ovc_debug_collect_winners_launch(const int32_t* anc, const int32_t* word, const float* running, int B, int width, int V, int k,
+                                     int64_t* chosen, float* score, hipStream_t stream) {
+    hipLaunchKernelGGL(collect_winners_kernel, dim3((B * k + 255) / 256), dim3(256), 0, stream, anc, word, running, B * k, k, width, V,
+                       chosen, score);
+    OVC_RETURN_IF_LAUNCH_FAILED();
+    return OVC_OK;
+}
+
 int ovc_masked_logp_launch(const float* logits, long ld_row, long ld_word, const float* row_max, const float* row_lsum,
                            const float* alive, int rows, int V, float* out, hipStream_t stream) {
     hipLaunchKernelGGL(masked_logp_kernel, dim3(rows), dim3(256), 0, stream, logits, ld_row, ld_word, row_max, row_lsum, alive, V, out);

@@ -223,6 +223,8 @@ int ovc_beam_update_launch(const BeamUpdateArgs& p, int B, hipStream_t stream);
 // transposed one.
 int ovc_beam_fused_update_launch(const BeamUpdateArgs& p, const float* stats, int nblk, int stats_ld, const float* running_in,
                                  long ld_row, long ld_word, int B, hipStream_t stream);
+int ovc_debug_collect_winners_launch(const int32_t* anc, const int32_t* word, const float* running, int B, int width, int V, int k,
+                                     int64_t* chosen, float* score, hipStream_t stream);
 int ovc_masked_logp_launch(const float* logits, long ld_row, long ld_word, const float* row_max, const float* row_lsum,
                            const float* alive, int rows, int V, float* out, hipStream_t stream);
 

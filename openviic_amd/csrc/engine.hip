@@ -815,6 +815,50 @@ extern "C" int ovc_beam_search_graph(const ovc_model* m, const float* features, 
     return OVC_OK;
 }
 
+// Test hook: ONE selection step of the fused path on caller-supplied decoder outputs -- the vocabulary product with its
+// log-softmax epilogue (transposed != 0: the fp32 engine's form, logits^T = fc . x^T; 0: the row-major form of the
+// split-precision modes) followed by beam_fused_update_kernel -- so that the selection can be checked against a stable sort
+// at the operator level (tests/test_ops_gpu.py).  x [B*width, d], fc [V, d], running / alive [B*width]; chosen [B, k] receives
+// flat indices beam * V + word in winning order, score [B, k] their scores.  scratch: ovc_debug_vocab_select_bytes.
+extern "C" size_t ovc_debug_vocab_select_bytes(int B, int width, int V, int k) {
+    if (B <= 0 || width <= 0 || V <= 0 || k <= 0) return 0;
+    const size_t R = (size_t)B * width, nblk = ((size_t)V + 31) / 32, ld = (nblk + 1) & ~(size_t)1;
+    return 4 * (((R + 3) & ~(size_t)3) * (((size_t)V + 3) & ~(size_t)3) + 2 * R * ld + 8 * (size_t)B * k + 64) + 4096;
+}
+
+extern "C" int ovc_debug_vocab_select(const float* x, const float* fc, const float* running, const float* alive, int B, int width,
+                                      int V, int d, int k, int transposed, void* scratch, size_t scratch_bytes, int64_t* chosen,
+                                      float* score, ovc_stream stream) {
+    if (!x || !fc || !running || !alive || !scratch || !chosen || !score || B <= 0 || width <= 0 || width > OVC_MAX_BEAM || k <= 0 ||
+        k > OVC_MAX_BEAM || V < k || d <= 0 || (d & 3) || (V + 31) / 32 > 512) return OVC_EINVAL;
+    if (scratch_bytes < ovc_debug_vocab_select_bytes(B, width, V, k) || !ovc_aligned16(scratch)) return OVC_EWORKSPACE;
+    TRY(ovc_device_guard());
+    hipStream_t s = ovc_hip_stream(stream);
+    const int rows = B * width, nblk = (V + 31) / 32, ld = (nblk + 1) & ~1, ldv = (V + 3) & ~3, ldt = (rows + 3) & ~3;
+    Bump a{reinterpret_cast<char*>(scratch), 0};
+    float* logits = a.take<float>(((size_t)(rows + 3) & ~(size_t)3) * ldv);
+    float* stats = a.take<float>(2 * (size_t)rows * ld);
+    float* alive_out = a.take<float>((size_t)B * k); float* running_out = a.take<float>((size_t)B * k);
+    float* lp_out = a.take<float>((size_t)B * k);
+    int32_t* hist_out = a.take<int32_t>((size_t)B * k); int32_t* anc_out = a.take<int32_t>((size_t)B * k);
+    int32_t* next_tok = a.take<int32_t>((size_t)B * k);
+    GemmArgs g{};
+    g.kchains = 4; g.K1 = d; g.lda1 = d; g.nseg = 1; g.stats_ld = ld;
+    if (transposed) {
+        g.A1 = fc; g.M = V; g.seg_n = rows; g.ldc = ldt; g.seg[0] = GemmSegment{x, nullptr, logits, nullptr, nullptr}; g.stats_t = stats;
+    } else {
+        g.A1 = x; g.M = rows; g.seg_n = V; g.ldc = ldv; g.seg[0] = GemmSegment{fc, nullptr, logits, nullptr, nullptr}; g.stats = stats;
+    }
+    TRY(ovc_gemm_launch(g, s));
+    BeamUpdateArgs bu{};
+    bu.logits = logits; bu.ld = ldv; bu.alive_in = alive; bu.alive_out = alive_out; bu.running_out = running_out;
+    bu.hist_out = hist_out; bu.lp_out = lp_out; bu.anc_out = anc_out; bu.next_tok = next_tok;
+    bu.hist_in = hist_out; bu.lp_in = lp_out; bu.anc_in = anc_out;                 // t = 0: nothing is copied from them
+    bu.width = width; bu.k = k; bu.V = V; bu.T = 1; bu.t = 0; bu.eos = -1;
+    TRY(ovc_beam_fused_update_launch(bu, stats, nblk, ld, running, transposed ? 1 : ldv, transposed ? ldt : 1, B, s));
+    return ovc_debug_collect_winners_launch(anc_out, hist_out, running_out, B, width, V, k, chosen, score, s);
+}
+
 extern "C" int ovc_graph_cache_clear(void) {
     std::lock_guard<std::mutex> lock(g_graph_mutex);
     for (auto& kv : g_graphs) destroy_entry(kv.second);

@@ -603,3 +603,89 @@ def test_operator_wrappers_reject_mismatched_shapes():
     with pytest.raises(native.OvcError):
         ops.beam_select(t(2, 3, 50), t(2, 3), torch.ones(2, 3, 1, device=DEV), None, 2, 9)   # beam wider than the ABI's maximum
     assert ops.linear(t(6, 32), t(16, 32), t(16)).shape == (6, 16)          # the well-formed call still works
+
+
+def _fused_select(lib, native, x, fc, running, alive, B, W, V, k, transposed):
+    chosen = torch.empty(B, k, dtype=torch.int64, device=DEV)
+    score = torch.empty(B, k, device=DEV)
+    scratch = torch.empty(lib.ovc_debug_vocab_select_bytes(B, W, V, k), dtype=torch.uint8, device=DEV)
+    rc = lib.ovc_debug_vocab_select(x.data_ptr(), fc.data_ptr(), running.data_ptr(), alive.data_ptr(), B, W, V, x.shape[1], k,
+                                    int(transposed), scratch.data_ptr(), scratch.numel(), chosen.data_ptr(), score.data_ptr(),
+                                    native.stream_handle())
+    assert rc == 0
+    return chosen.cpu(), score.cpu()
+
+
+@pytest.mark.parametrize("B,W,V,k,d", [(6, 5, 10201, 5, 64), (9, 1, 10201, 5, 64), (3, 3, 53, 3, 32), (4, 8, 999, 8, 64),
+                                       (5, 5, 16384, 5, 32), (2, 2, 40, 2, 32)])
+def test_fused_selection_from_block_pieces_matches_a_stable_sort(B, W, V, k, d):
+    """The engine's selection never reads the logits back: the vocabulary GEMM's epilogue leaves (max, sum exp) per 32-word
+    block and beam_fused_update_kernel picks the image's k winners from those pieces plus a few gathered blocks
+    (reference semantics: models/modules/beam_search.py:45-59).  Operands with small dyadic values make every logit EXACT in
+    fp32, so the winners must be those of a stable descending sort -- ties inside a row broken by the lower word index --
+    for live and frozen beams, in both orientations of the product (transposed = the fp32 engine's, row-major = the
+    split-precision modes')."""
+    from openviic_amd import native
+    lib = native.load()
+    g = torch.Generator().manual_seed(V + 7 * W + B)
+    x = torch.randint(-4, 5, (B * W, d), generator=g).float() / 8
+    fc = torch.randint(-2, 3, (V, d), generator=g).float() / 2
+    fc[min(40, V - 1)] = fc[7]                     # exact ties inside every row: the lower word index must win
+    fc[V - 1] = fc[3]
+    running = torch.randn(B, W, generator=g)
+    alive = (torch.rand(B, W, generator=g) > 0.3).float()
+    alive[:, 0] = 1
+    logits = x.double() @ fc.double().T
+    assert torch.equal(logits.float().double(), logits)                       # exact in fp32
+    logp = torch.log_softmax(logits, -1).view(B, W, V)
+    cand = running.double()[:, :, None] + logp
+    frozen = torch.full_like(cand, -999.0)
+    frozen[:, :, 0] = running.double()
+    cand = torch.where(alive[:, :, None] > 0, cand, frozen)
+    want_val, want_idx = torch.sort(cand.view(B, -1), dim=-1, descending=True, stable=True)
+    margin = (want_val[:, :k] - want_val[:, 1:k + 1]).abs()
+    got = {}
+    for transposed in (1, 0):
+        idx, val = _fused_select(lib, native, x.to(DEV), fc.to(DEV), running.to(DEV).contiguous(), alive.to(DEV).contiguous(), B, W, V, k,
+                                 transposed)
+        got[transposed] = (idx, val)
+        np.testing.assert_allclose(val.numpy(), want_val[:, :k].numpy(), rtol=0, atol=2e-5)
+        # winners: identical wherever the next candidate is not within fp32 noise of the chosen one, or ties exactly with it
+        # inside one row (then the order of the stable sort is the rule)
+        for b in range(B):
+            for j in range(k):
+                same_row_tie = j + 1 < W * V and want_idx[b, j] // V == want_idx[b, j + 1] // V and margin[b, j] == 0
+                prev_tie = j > 0 and want_idx[b, j] // V == want_idx[b, j - 1] // V and margin[b, j - 1] == 0
+                if margin[b, j] > 1e-5 and (j == 0 or margin[b, j - 1] > 1e-5) or same_row_tie or prev_tie:
+                    if (j == 0 or margin[b, j - 1] > 1e-5 or prev_tie) and (margin[b, j] > 1e-5 or same_row_tie):
+                        assert idx[b, j] == want_idx[b, j], (b, j, idx[b], want_idx[b, :k + 1], want_val[b, :k + 1])
+    # the two orientations sum a block's exponentials in different (each fixed) orders: same winners, scores to rounding
+    assert torch.equal(got[1][0], got[0][0])
+    np.testing.assert_allclose(got[1][1].numpy(), got[0][1].numpy(), rtol=0, atol=2e-6)
+
+
+def test_fused_selection_massive_ties_frozen_beams_and_nan_rows():
+    """Uniform rows (a live beam fed <pad>: thousands of exactly equal candidates -> the exhaustive fallback), images whose
+    beams are all frozen, and NaN rows (an image without valid regions) -- lowest flat index first, in-range indices always."""
+    from openviic_amd import native
+    lib = native.load()
+    B, W, V, k, d = 4, 5, 10201, 5, 32
+    g = torch.Generator().manual_seed(3)
+    x = torch.randint(-4, 5, (B * W, d), generator=g).float() / 8
+    fc = torch.randint(-2, 3, (V, d), generator=g).float() / 2
+    x[0:W] = 0                                          # image 0: every row uniform -> all candidates of a row tie
+    running = torch.tensor([[0.0, -1.0, -2.0, -3.0, -4.0]] * B)
+    alive = torch.ones(B, W)
+    alive[1] = 0                                        # image 1: every beam frozen
+    x[2 * W:3 * W] = float("nan")                       # image 2: NaN logits
+    idx, val = _fused_select(lib, native, x.to(DEV), fc.to(DEV), running.to(DEV), alive.to(DEV), B, W, V, k, 1)
+    np.testing.assert_array_equal(idx[0].numpy(), np.arange(k))                         # beam 0 (best running), words 0..k-1
+    np.testing.assert_allclose(val[0].numpy(), -np.log(V), rtol=1e-6)
+    # frozen beams offer word 0 at their running score and -999 for every other word: the k beams' word 0, best running first
+    np.testing.assert_array_equal(idx[1].numpy(), np.arange(k) * V)
+    np.testing.assert_array_equal(val[1].numpy(), running[1].numpy())
+    assert ((idx[2] >= 0) & (idx[2] < W * V)).all()                                       # arbitrary but in range
+    logits = x[3 * W:].double() @ fc.double().T
+    cand = (running[3].double()[:, None] + torch.log_softmax(logits, -1)).view(-1)
+    want_val, want_idx = torch.sort(cand, descending=True, stable=True)
+    np.testing.assert_allclose(val[3].numpy(), want_val[:k].numpy(), rtol=0, atol=2e-5)
