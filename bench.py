@@ -74,7 +74,8 @@ def parse():
                          "small launches, so several batches in flight fill the chip better than one")
     ap.add_argument("--tune-concurrency", type=int, default=0,
                     help="GEMM tuning objective of the timed region's engine: tilings ranked by the time of this many "
-                         "co-running copies (0 = 2 with three or more streams, else 1).  Changes speed only, never a bit.")
+                         "co-running copies (0 = the stream count, at most 4, with three or more streams, else 1).  Changes speed "
+                         "only, never a bit.")
     ap.add_argument("--precision", default="f32", choices=["f32", "bf16x6", "f16x3"],
                     help="GEMM arithmetic.  f32 (default) = fp32 MFMA, the parity mode and the only headline.  The others are the "
                          "opt-in split-precision modes (bf16 planes, fp32 accumulate), reported separately: NOT bit-identical to f32.")
@@ -262,7 +263,8 @@ def main():
     # kernel-scoped roofline belongs to -- uses the table measured in isolation.  All tilings of a K-order class give the
     # same bits, so this moves no result.
     from openviic_amd.engine import CaptionEngine
-    objective = args.tune_concurrency or (2 if len(streams) >= 3 else 1)
+    # (round 3, one box, two alternating rounds: objective 1 / 2 / 3 / 4 = 22.8-23.0k / 23.2-23.3k / 23.3-23.4k / 23.44-23.46k)
+    objective = args.tune_concurrency or (min(len(streams), 4) if len(streams) >= 3 else 1)
     engine_timed = CaptionEngine(model, tune_concurrency=objective, precision=args.precision)
     engine_single = engine_timed if objective == 1 else CaptionEngine(model, tune_concurrency=1, precision=args.precision)
     model._engine = engine_timed
