@@ -37,6 +37,7 @@ class BaseTransformer(Module):
         self.encoder = build_encoder(config.ENCODER)
         self.decoder = build_decoder(config.DECODER, vocab)
         self._engine = None
+        self._predict_pipeline = None
 
     def init_weights(self):
         for p in self.parameters():
@@ -46,6 +47,7 @@ class BaseTransformer(Module):
     def _apply(self, fn, *args, **kwargs):
         out = super()._apply(fn, *args, **kwargs)
         self._engine = None                       # parameter storage may have moved
+        self._predict_pipeline = None             # (data.predict_feature_files: streams and pinned buffers of the old device)
         if any(True for _ in self.parameters()):
             self.device = next(self.parameters()).device
         return out
