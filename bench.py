@@ -220,6 +220,11 @@ def cpu_baseline(cfg, sd, variant, beam, sample, repeats):
 
 def main():
     args = parse()
+    # stdout carries exactly ONE line, the JSON: libraries that chat on stdout (RCCL prints a version banner when its first
+    # communicator comes up) are sent to stderr until the line is printed
+    sys.stdout.flush()
+    stdout_fd = os.dup(1)
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -475,7 +480,10 @@ def main():
             result["opt_in_precision"] = also
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(cfg, sd, variant, k, args.cpu_sample, args.cpu_repeats)
+        sys.stdout.flush()
+        os.dup2(stdout_fd, 1)
         print(json.dumps(result), flush=True)
+        os.dup2(2, 1)
     if distributed:
         dist.barrier()
         dist.destroy_process_group()
