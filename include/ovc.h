@@ -256,7 +256,8 @@ const char* ovc_profile_kernel_name(int tiling);   /* "" past the last tiling */
 
 /* GEMM K-order classes.  fp32 addition is not associative and beam search decides on fp32 comparisons, so the
  * order in which a product sums over K is part of its definition here, never a tuning outcome:
- *   kchains = 1   one fmaf chain over k (ovc_linear; the engine's M = B*N encoder-side products);
+ *   kchains = 1   one fmaf chain over k (ovc_linear; the engine's M = B*N encoder-side products, and the fp32 engine's
+ *                 vocabulary projection, which runs transposed -- M = V rows);
  *   kchains = 4   four interleaved chains summed in chain order (the engine's M = B*beam decode-step products);
  *   ksplit  = s   K cut into s contiguous slices whose raw partial products the consuming LayerNorm sums in
  *                 slice order (engine only; a fixed function of K).
@@ -271,9 +272,10 @@ const char* ovc_profile_kernel_name(int tiling);   /* "" past the last tiling */
  * that shape and class use it, and shapes whose M is within a factor of two of a measured one borrow its entry.
  * scratch: >= 4*(M*K + nseg*seg_n*K + ksplit*M*nseg*seg_n) + 64 bytes of device memory (contents are used as
  * operands); for the split-precision classes, nseg * ovc_split_weight_bytes(seg_n, K, kchains - 100) more bytes make the
- * measurement use pre-cut weight planes (what the engine runs when ovc_lin::planes are set); a single-segment
- * kchains = 4 product with seg_n >= 4096 (the engine's vocabulary projection) is measured with its log-softmax epilogue
- * when 8 * M * (seg_n / 32 + 4) more bytes are there.
+ * measurement use pre-cut weight planes (what the engine runs when ovc_lin::planes are set).  `epilogue`: 0 = the plain
+ * product; 1 / 2 = measured with the log-softmax epilogue the engine's vocabulary projection carries (1: row-major form,
+ * 8 * M * (seg_n / 32 + 4) more scratch bytes; 2: transposed form, 8 * seg_n * (M / 32 + 4)) -- the seventh value
+ * ovc_engine_gemm_shapes reports.
  * `objective` (1..8) = what is minimised: the time of that many identical products co-running in one launch.  1 ranks
  * tilings by isolated latency, which favours many small tiles; with several independent batches in flight on different
  * streams, rank with objective = that number: fewer, larger tiles then win because they spend fewer CU-seconds and less
@@ -281,7 +283,7 @@ const char* ovc_profile_kernel_name(int tiling);   /* "" past the last tiling */
  * "current objective" any more, so host threads with different objectives cannot cross their entries); which table an
  * engine call consults is ovc_model::tune_objective.
  * SYNCHRONISES the stream -- set-up time only.  Thread-safe. */
-int ovc_gemm_tune(int M, int seg_n, int nseg, int K, int kchains, int ksplit, int objective, void* scratch,
+int ovc_gemm_tune(int M, int seg_n, int nseg, int K, int kchains, int ksplit, int objective, int epilogue, void* scratch,
                   size_t scratch_bytes, ovc_stream stream);
 long ovc_gemm_tune_calls(void);        /* measurements run so far in this process */
 
@@ -291,8 +293,8 @@ long ovc_gemm_tune_calls(void);        /* measurements run so far in this proces
 int ovc_gemm_tuned_get(int M, int seg_n, int nseg, int K, int kchains, int ksplit, int objective, int near);
 int ovc_gemm_tuned_set(int M, int seg_n, int nseg, int K, int kchains, int ksplit, int objective, int tiling);
 
-/* The distinct GEMMs the engine issues for batch B, N regions, beam k: up to `capacity` records of six int32
- * (M, seg_n, nseg, K, kchains, ksplit) are written to `shapes`; returns the number of distinct shapes (which may
+/* The distinct GEMMs the engine issues for batch B, N regions, beam k: up to `capacity` records of seven int32
+ * (M, seg_n, nseg, K, kchains, ksplit, epilogue) are written to `shapes`; returns the number of distinct shapes (which may
  * exceed capacity) or a negative OVC_E* code.  Host only: no launch, no device access. */
 int ovc_engine_gemm_shapes(const ovc_model* m, int B, int N, int k, int32_t* shapes, int capacity);
 

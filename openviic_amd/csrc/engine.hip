@@ -247,7 +247,7 @@ int decode_ksplit(int K) {
     return s;
 }
 
-using GemmShape = std::array<int, 6>;               // M, seg_n, nseg, K, kchains, ksplit
+using GemmShape = std::array<int, 7>;               // M, seg_n, nseg, K, kchains, ksplit, epilogue (0 plain, 1 stats, 2 stats_t)
 
 struct Engine {
     const ovc_model* m;
@@ -269,7 +269,7 @@ struct Engine {
         if (m->precision == 4 && gemm_class == 0) a.kchains = 103;
         a.objective = m->tune_objective;
         if (dry) {
-            const GemmShape sh{a.M, a.seg_n, a.nseg, a.K1 + a.K2, a.kchains, a.ksplit > 1 ? a.ksplit : 1};
+            const GemmShape sh{a.M, a.seg_n, a.nseg, a.K1 + a.K2, a.kchains, a.ksplit > 1 ? a.ksplit : 1, a.stats ? 1 : (a.stats_t ? 2 : 0)};
             if (std::find(dry->begin(), dry->end(), sh) == dry->end()) dry->push_back(sh);
             return OVC_OK;
         }
@@ -563,6 +563,14 @@ int run_decode_step(Engine& e, Workspace& w, int B, int N, int k, int t, int ret
     const bool transposed = fused_select && m->precision == 0 && !row_major;
     const int ldt = (rows + 3) & ~3;               // row stride of logits^T
     {
+        // K-order class of THIS call site: the transposed product has M = V rows -- thousands of output tiles whatever the batch
+        // -- so it needs no chains spread over waves and takes the one-chain class of the other large-M products (a quarter of
+        // the accumulator registers: +1.2 % captions/s with four batches in flight, +0.5 % on one stream, same-box A/B).  The
+        // row-major form of the split-precision modes keeps its class.  OVC_DEBUG_VOCAB_KCHAINS=4: A/B switch (changes the
+        // logits' low-order bits).
+        static const int vocab_chains = [] { const char* v = getenv("OVC_DEBUG_VOCAB_KCHAINS"); return v ? atoi(v) : 0; }();
+        const int saved_chains = e.kchains;
+        if (transposed) e.kchains = vocab_chains == 4 ? 4 : 1;
         GemmArgs g{};
         if (transposed) {
             g.A1 = m->fc; g.lda1 = d; g.K1 = d; g.M = m->vocab; g.seg_n = rows; g.nseg = 1; g.ldc = ldt;
@@ -574,6 +582,7 @@ int run_decode_step(Engine& e, Workspace& w, int B, int N, int k, int t, int ret
             g.stats = fused_select ? w.stats : nullptr; g.stats_ld = (nblk + 1) & ~1;
         }
         TRY(e.gemm(g));
+        e.kchains = saved_chains;
     }
     const long ld_row = transposed ? 1 : ldv, ld_word = transposed ? ldt : 1;
     BeamUpdateArgs bu{};
@@ -632,7 +641,7 @@ extern "C" int ovc_engine_gemm_shapes(const ovc_model* m, int B, int N, int k, i
     TRY(project_cross_kv(e, w, B, N));
     for (int t = 0; t < (m->max_len < 2 ? m->max_len : 2); ++t) TRY(run_decode_step(e, w, B, N, k, t, 0));   // step 0: B rows, later steps: B*k
     for (size_t i = 0; i < found.size() && (int)i < capacity; ++i)
-        for (int j = 0; j < 6; ++j) shapes[i * 6 + j] = found[i][j];
+        for (int j = 0; j < 7; ++j) shapes[i * 7 + j] = found[i][j];
     return (int)found.size();
 }
 

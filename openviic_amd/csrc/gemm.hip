@@ -740,9 +740,9 @@ int ovc_gemm_launch(const GemmArgs& a, hipStream_t stream, const GemmLaunchOpts&
 // Measure every tiling of one K-order class on one GEMM shape and remember the fastest (process-wide).  Synchronises
 // the stream: call it at set-up time, never inside a captured or latency-sensitive region.  The choice changes speed
 // only: all tilings of a class produce the same bits.
-extern "C" int ovc_gemm_tune(int M, int seg_n, int nseg, int K, int kchains, int ksplit, int objective, void* scratch,
+extern "C" int ovc_gemm_tune(int M, int seg_n, int nseg, int K, int kchains, int ksplit, int objective, int epilogue, void* scratch,
                              size_t scratch_bytes, ovc_stream stream) {
-    if (objective < 1 || objective > 8) return OVC_EINVAL;
+    if (objective < 1 || objective > 8 || epilogue < 0 || epilogue > 2) return OVC_EINVAL;
     if (const int rc = ovc_device_guard()) return rc;
     if (M <= 0 || seg_n <= 0 || nseg <= 0 || nseg > OVC_MAX_SEGMENTS || K <= 0 || (K & 3)) return OVC_EINVAL;
     if (!class_ok(kchains) || ksplit < 1 || ksplit > kMaxKSplit || (ksplit > 1 && (nseg != 1 || K % (ksplit * 32)))) return OVC_EINVAL;
@@ -769,8 +769,11 @@ extern "C" int ovc_gemm_tune(int M, int seg_n, int nseg, int K, int kchains, int
     // Wide single-segment products of the decode class (the engine has one: the vocabulary projection) run with the
     // log-softmax epilogue (GemmArgs::stats); rank their tilings WITH it when the scratch buffer has room behind the outputs
     // (its cost depends on the tiling's register budget: the K-tile-64 instance loses 5 us to it, the K-tile-32 one 4)
-    if (kchains == 4 && nseg == 1 && ksplit == 1 && (seg_n >= 4096 || M >= 4096)) {
-        const bool transposed = M >= 4096;                     // the fp32 engine runs the product transposed (words = rows)
+    // A product that runs with the log-softmax epilogue (GemmArgs::stats / stats_t: the engine's vocabulary projection) is
+    // ranked WITH it when the scratch buffer has room behind the outputs: its cost depends on the tiling's register budget
+    // (the K-tile-64 instance loses 5 us to the row-major form, the K-tile-32 one 4).  epilogue: 1 = stats, 2 = stats_t.
+    if ((epilogue == 1 || epilogue == 2) && nseg == 1 && ksplit == 1) {
+        const bool transposed = epilogue == 2;
         const int ld = (((transposed ? M : seg_n) + 31) / 32 + 1) & ~1;
         const size_t entries = (size_t)(transposed ? seg_n : M) * ld;
         float* S = C + ((nc + 3) & ~(size_t)3);

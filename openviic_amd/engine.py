@@ -218,15 +218,15 @@ class CaptionEngine:
 
     # -- GEMM tiling selection ------------------------------------------------------------------
     def gemm_shapes(self, B, N, k):
-        """(M, seg_n, nseg, K, kchains, ksplit) of every GEMM the engine issues for batch B, N regions, beam k --
+        """(M, seg_n, nseg, K, kchains, ksplit, epilogue) of every GEMM the engine issues for batch B, N regions, beam k --
         enumerated by the library itself (``ovc_engine_gemm_shapes`` walks the real launch sequence in dry mode)."""
         cap = 64
         while True:
-            buf = (ctypes.c_int32 * (6 * cap))()
+            buf = (ctypes.c_int32 * (7 * cap))()
             n = self.lib.ovc_engine_gemm_shapes(ctypes.byref(self.desc), B, N, k, buf, cap)
             check(min(n, 0), "ovc_engine_gemm_shapes")
             if n <= cap:
-                return sorted(tuple(buf[6 * i + j] for j in range(6)) for i in range(n))
+                return sorted(tuple(buf[7 * i + j] for j in range(7)) for i in range(n))
             cap = n
 
     def tune(self, B, N, k):
@@ -253,22 +253,23 @@ class CaptionEngine:
             for shape in shapes:
                 name = ",".join(map(str, shape)) + "@%d" % objective
                 if name in cache:
-                    self.lib.ovc_gemm_tuned_set(*shape, objective, int(cache[name]))
-        todo = [sh for sh in shapes if self.lib.ovc_gemm_tuned_get(*sh, objective, 1) < 0]
+                    self.lib.ovc_gemm_tuned_set(*shape[:6], objective, int(cache[name]))
+        todo = [sh for sh in shapes if self.lib.ovc_gemm_tuned_get(*sh[:6], objective, 1) < 0]
         if todo:
             # operands + output (K-split shapes: one partial output per slice)
             # (+ room for pre-cut weight planes in the split-precision classes: the tuner then ranks the instances the engine runs)
             # (+ room for the log-softmax block pieces of a wide decode-class product: it is then ranked with that epilogue)
-            need = max(4 * (m * kk + sn * ns * kk + m * sn * ns * ks) + 256 + 8 * m * (sn // 32 + 4) +
-                       (ns * self.lib.ovc_split_weight_bytes(sn, kk, kc - 100) if kc > 100 else 0) for m, sn, ns, kk, kc, ks in todo)
+            need = max(4 * (m * kk + sn * ns * kk + m * sn * ns * ks) + 256 +
+                       (8 * m * (sn // 32 + 4) if ep == 1 else 8 * sn * (m // 32 + 4) if ep == 2 else 0) +
+                       (ns * self.lib.ovc_split_weight_bytes(sn, kk, kc - 100) if kc > 100 else 0) for m, sn, ns, kk, kc, ks, ep in todo)
             scratch = torch.empty(need // 4 + 16, dtype=torch.float32, device=self.device).normal_()
             for sh in todo:
-                check(self.lib.ovc_gemm_tune(*sh, objective, scratch.data_ptr(), scratch.numel() * 4, native.stream_handle()),
+                check(self.lib.ovc_gemm_tune(*sh[:6], objective, sh[6], scratch.data_ptr(), scratch.numel() * 4, native.stream_handle()),
                       "ovc_gemm_tune{}".format(sh))
             torch.cuda.current_stream().synchronize()
         if cache_path and todo:
             for shape in shapes:
-                t = self.lib.ovc_gemm_tuned_get(*shape, objective, 0)
+                t = self.lib.ovc_gemm_tuned_get(*shape[:6], objective, 0)
                 if t >= 0:
                     cache[",".join(map(str, shape)) + "@%d" % objective] = t
             os.makedirs(os.path.dirname(os.path.abspath(cache_path)), exist_ok=True)

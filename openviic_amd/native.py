@@ -93,7 +93,7 @@ SIGNATURES = {
     "ovc_encode": (c_int, [POINTER(Model), c_void_p, c_void_p, c_int, c_int, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]),
     "ovc_beam_search": (c_int, [POINTER(Model), c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_size_t,
                                 c_void_p, c_void_p, c_void_p, c_void_p]),
-    "ovc_gemm_tune": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
+    "ovc_gemm_tune": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "ovc_gemm_tune_calls": (c_long, []),
     "ovc_gemm_tuned_get": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
     "ovc_gemm_tuned_set": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int]),

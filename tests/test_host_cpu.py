@@ -205,24 +205,27 @@ def test_engine_enumerates_its_gemm_shapes_with_fixed_k_order_classes():
 
     def shapes(B, N, k, **over):
         d = _desc(**over)
-        buf = (ctypes.c_int32 * (6 * 64))()
+        buf = (ctypes.c_int32 * (7 * 64))()
         n = lib.ovc_engine_gemm_shapes(ctypes.byref(d), B, N, k, buf, 64)
         assert 0 < n <= 64
-        return {tuple(buf[6 * i + j] for j in range(6)) for i in range(n)}
+        found = {tuple(buf[7 * i + j] for j in range(7)) for i in range(n)}
+        # the seventh value marks the product that carries the log-softmax epilogue: the transposed vocabulary projection only
+        assert {s[:2] for s in found if s[6]} <= {(10201, B), (10201, B * k)} and all(s[6] == 2 for s in found if s[0] == 10201)
+        return {s[:6] for s in found}
     got = shapes(256, 50, 5)
     assert got == {
         (12800, 512, 1, 2048, 1, 1), (12800, 512, 3, 512, 1, 1), (12800, 512, 1, 512, 1, 1), (12800, 2048, 1, 512, 1, 1),
         (12800, 512, 6, 512, 1, 1),                                       # cross K/V of the three decoder layers
         (256, 512, 3, 512, 4, 1), (256, 512, 1, 512, 4, 2), (256, 512, 1, 512, 4, 1), (256, 2048, 1, 512, 4, 1),
-        (256, 512, 1, 2048, 4, 4), (10201, 256, 1, 512, 4, 1),           # vocabulary product, transposed: logits^T = fc . x^T
+        (256, 512, 1, 2048, 4, 4), (10201, 256, 1, 512, 1, 1),           # vocabulary product, transposed (logits^T = fc . x^T): one chain
         (1280, 512, 3, 512, 4, 1), (1280, 512, 1, 512, 4, 2), (1280, 512, 1, 512, 4, 1), (1280, 2048, 1, 512, 4, 1),
-        (1280, 512, 1, 2048, 4, 4), (10201, 1280, 1, 512, 4, 1)}
+        (1280, 512, 1, 2048, 4, 4), (10201, 1280, 1, 512, 1, 1)}
     half = shapes(128, 50, 5)
     # same products, same K-order classes, same K splits at any batch size (the transposed vocabulary product carries the
     # beam rows in its N: compared by its K / class / split)
-    norm = lambda shapes_: {(s[1:] if s[0] != 10201 else ("vocab",) + s[3:]) for s in shapes_ if s[4] == 4}
+    norm = lambda shapes_: {(s[1:] if s[0] != 10201 else ("vocab",) + s[3:]) for s in shapes_ if s[4] == 4 or s[0] == 10201}
     assert norm(half) == norm(got)
-    assert {s[4] for s in got if s[0] == 12800} == {1}
+    assert {s[4] for s in got if s[0] == 12800} == {1} and {s[4] for s in got if s[0] == 10201} == {1}
     meshed = shapes(16, 50, 5, enc_kind=native.ENC_MULTILEVEL, dec_kind=native.DEC_MESHED, n_levels=3)
     assert (80, 512, 3, 1024, 4, 1) in meshed and (240, 512, 1, 512, 4, 1) in meshed      # level gates; stacked output projection
 

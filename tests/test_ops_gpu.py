@@ -520,11 +520,11 @@ def test_tuner_only_ranks_inside_the_class_and_borrows_neighbouring_shapes():
     for chains in (1, 4, 104):
         assert lib.ovc_gemm_tuned_get(M, N, 1, K, chains, 1, 1, 0) == -1
         calls = lib.ovc_gemm_tune_calls()
-        assert lib.ovc_gemm_tune(M, N, 1, K, chains, 1, 1, scratch.data_ptr(), scratch.numel() * 4, native.stream_handle()) == 0
+        assert lib.ovc_gemm_tune(M, N, 1, K, chains, 1, 1, 0, scratch.data_ptr(), scratch.numel() * 4, native.stream_handle()) == 0
         assert lib.ovc_gemm_tune_calls() == calls + 1
         t = lib.ovc_gemm_tuned_get(M, N, 1, K, chains, 1, 1, 0)
         assert t >= 0 and dict((i, c) for i, _, c in _tilings_cached(lib))[t] == chains
-        assert lib.ovc_gemm_tune(M, N, 1, K, chains, 1, 1, scratch.data_ptr(), scratch.numel() * 4, native.stream_handle()) == 0
+        assert lib.ovc_gemm_tune(M, N, 1, K, chains, 1, 1, 0, scratch.data_ptr(), scratch.numel() * 4, native.stream_handle()) == 0
         assert lib.ovc_gemm_tune_calls() == calls + 1                       # already measured: nothing runs
         assert lib.ovc_gemm_tuned_get(M + 40, N, 1, K, chains, 1, 1, 0) == -1     # exact look-up misses ...
         assert lib.ovc_gemm_tuned_get(M + 40, N, 1, K, chains, 1, 1, 1) == t      # ... the near one borrows the neighbour
@@ -535,7 +535,7 @@ def test_tuner_only_ranks_inside_the_class_and_borrows_neighbouring_shapes():
         wrong = next(i for i, _, c in _tilings_cached(lib) if c != chains)
         assert lib.ovc_gemm_tuned_set(M, N, 1, K, chains, 1, 1, wrong) != 0    # a tiling of the other class is refused
         assert lib.ovc_gemm_tuned_set(M, N, 1, K, chains, 1, 9, t) != 0        # objectives are 1..8
-    assert lib.ovc_gemm_tune(M, N, 1, K, 102, 1, 1, scratch.data_ptr(), scratch.numel() * 4, native.stream_handle()) != 0   # deleted class
+    assert lib.ovc_gemm_tune(M, N, 1, K, 102, 1, 1, 0, scratch.data_ptr(), scratch.numel() * 4, native.stream_handle()) != 0   # deleted class
     assert lib.ovc_gemm_tuned_set(16, 512, 3, 2048, 4, 2, 1, 7) != 0           # segmented outputs cannot split
     assert lib.ovc_gemm_tuned_set(16, 512, 1, 2048, 4, 8, 1, 7) != 0           # more than 4 slices
 
