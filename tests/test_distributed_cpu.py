@@ -1,4 +1,4 @@
-"""The N > 1 path (shard -> decode -> all-gather of token ids) over gloo, world_size 2, on CPU.
+"""The N > 1 path (shard -> decode -> all-gather of token ids) over gloo, world_size 2 and 4, on CPU.
 
 The decode function is the CPU oracle here (the HIP engine needs a GPU); what is under test is the
 sharding, padding and the collective in ``openviic_amd.distributed``.
@@ -42,15 +42,14 @@ def _worker(rank, world, port, total, out_dir):
     dist.destroy_process_group()
 
 
-def _run(total, tmp_path):
-    world = 2
+def _run(total, tmp_path, world=2):
     mp.spawn(_worker, args=(world, _free_port(), total, str(tmp_path)), nprocs=world, join=True)
     cfg, vocab, sd, feats, _ = tiny_case("standard_transformer", B=total)
     want_ids, want_logp = OracleCaptioner(cfg, sd, len(vocab), vocab.max_caption_length).beam_search(feats, 3)
     for rank in range(world):
         np.testing.assert_array_equal(np.load(tmp_path / ("ids_%d.npy" % rank)), want_ids.numpy())
         np.testing.assert_allclose(np.load(tmp_path / ("logp_%d.npy" % rank)), want_logp.numpy(), rtol=1e-5, atol=1e-6)
-        assert np.load(tmp_path / ("calls_%d.npy" % rank)).tolist() == [(total + 1) // 2]
+        assert np.load(tmp_path / ("calls_%d.npy" % rank)).tolist() == [(total + world - 1) // world]
 
 
 def test_even_shards(tmp_path):
@@ -59,6 +58,16 @@ def test_even_shards(tmp_path):
 
 def test_ragged_last_shard_is_padded(tmp_path):
     _run(5, tmp_path)
+
+
+def test_four_ranks_with_a_short_and_an_empty_shard(tmp_path):
+    """BASELINE config 5 shards over 8 GPUs; more than two ranks exercise the ordering of the gathered shards, and 5 images over
+    4 ranks leave rank 2 one image and rank 3 NONE: its whole shard is zero-row padding images, decoded and dropped."""
+    _run(5, tmp_path, world=4)
+
+
+def test_four_ranks_even(tmp_path):
+    _run(8, tmp_path, world=4)
 
 
 def test_shard_bounds():
