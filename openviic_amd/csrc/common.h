@@ -95,48 +95,6 @@ struct GemmSegment {
                          // read by each wave straight from memory -- or nullptr: the kernel cuts W itself, through LDS
 };
 
-// Lazy LayerNorm (GemmArgs::ln_out / ln_in): a row's mean and 1 / std from its per-32-column-block (sum, sum of squared deviations
-// from the block mean) pairs, combined in block order (Chan et al.) -- every reader of a row's pairs gets the same bits.
-__device__ __forceinline__ void ovc_ln_row_moments(const f32x2* __restrict__ st, int nb, float eps, float& mean, float& rstd) {
-    // the pairs are fetched 16 at a time with nothing between the loads (a run-time trip count around single loads would pay one
-    // memory round trip per block); d_model = 512 is one such batch, kept in registers for both passes
-    const float width = 32.f * (float)nb;
-    float sum = 0.f, m2 = 0.f;
-    if (nb <= 16) {
-        f32x2 e[16];
-#pragma unroll
-        for (int j = 0; j < 16; ++j) e[j] = st[min(j, nb - 1)];
-#pragma unroll
-        for (int j = 0; j < 16; ++j) sum += j < nb ? e[j][0] : 0.f;
-        mean = sum / width;
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const float dm = e[j][0] * (1.f / 32.f) - mean;
-            m2 += j < nb ? e[j][1] + 32.f * dm * dm : 0.f;
-        }
-    } else {
-        for (int b0 = 0; b0 < nb; b0 += 16) {
-            f32x2 e[16];
-#pragma unroll
-            for (int j = 0; j < 16; ++j) e[j] = st[min(b0 + j, nb - 1)];
-#pragma unroll
-            for (int j = 0; j < 16; ++j) sum += b0 + j < nb ? e[j][0] : 0.f;
-        }
-        mean = sum / width;
-        for (int b0 = 0; b0 < nb; b0 += 16) {
-            f32x2 e[16];
-#pragma unroll
-            for (int j = 0; j < 16; ++j) e[j] = st[min(b0 + j, nb - 1)];
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const float dm = e[j][0] * (1.f / 32.f) - mean;
-                m2 += b0 + j < nb ? e[j][1] + 32.f * dm * dm : 0.f;
-            }
-        }
-    }
-    rstd = 1.0f / sqrtf(m2 / width + eps);
-}
-
 struct GemmArgs {
     const float* A1;     // [M, K1], row stride lda1
     const float* A2;     // [M, K2], row stride lda2 (nullptr when K2 == 0)
@@ -164,20 +122,6 @@ struct GemmArgs {
     float* stats_t;      // the same pieces for a TRANSPOSED product (rows of C are the words, columns the beam rows): per (column n,
                          // 32-row block) the maximum and sum exp over the block's rows, [seg_n][stats_ld] float2.  A lane of the
                          // accumulator then holds 16 words of ONE beam row, so the reductions are in-register (one half-wave swap each)
-    // Lazy LayerNorm (decode step, fp32 classes, nseg == 1, no K split, 32 | seg_n): the AddNorm behind a projection is never
-    // materialised.  The PRODUCER leaves its raw rows y plus, per (row, 32-column block), the block's sum and its sum of squared
-    // deviations from the block mean (ln_out); a CONSUMER turns them into the row's mean / rstd (fixed block order, Chan's
-    // combination) and applies the normalisation where it reads y: as the A operand through the fold
-    //   LN(y) W^T + b  =  rstd * (y (W gamma)^T - mean * u) + c,   u[n] = sum_k W[n,k] gamma[k],  c = W beta + b
-    // (fold_u / fold_c, seg[0].W = the gamma-scaled weight, seg[0].bias ignored), and / or as the residual (res_g / res_b: R holds y).
-    float* ln_out;       // [M][seg_n / 32] float2 (sum, M2) of the finished outputs
-    const float* ln_in;  // [M][ln_in_blocks] float2 of the lazily normalised operand's rows
-    int ln_in_blocks;    // its width / 32
-    float ln_eps;
-    const float* fold_u; // [seg_n]
-    const float* fold_c; // [seg_n]
-    const float* res_g;  // [seg_n] gamma / beta of the LayerNorm the residual rows still owe
-    const float* res_b;
     int objective;       // which tuning table to consult: 0 / 1 = measured in isolation, c > 1 = measured with c co-running copies
                          // (speed only: every tiling of the class gives the same bits)
     GemmSegment seg[OVC_MAX_SEGMENTS];
@@ -195,18 +139,11 @@ int ovc_gemm_launch(const GemmArgs& args, hipStream_t stream, const GemmLaunchOp
 int ovc_gemm_pick_tiling(const GemmArgs& args, const GemmLaunchOpts& opts = GemmLaunchOpts{});   // tiling ovc_gemm_launch will use
 int ovc_gemm_tiling_class(int tiling);               // chains of a tiling's K-order class (0 = no such tiling)
 constexpr int kMaxKSplit = 4;
-// Rows whose LayerNorm is still owed (lazy LayerNorm, GemmArgs::ln_out): their per-block moments and that LayerNorm's affine.
-struct LazyRows {
-    const float* stats = nullptr;   // [rows][blocks] float2
-    int blocks = 0;                 // row width / 32
-    const float* g = nullptr;
-    const float* b = nullptr;
-};
 // LayerNorm(sum_s parts[s] + bias + residual), nparts in {2, 4}, bias and residual required: the consumer side of
-// a K-split GEMM (rowops.hip).  lazy.stats set: the residual rows are raw and normalised as they are read.
+// a K-split GEMM (rowops.hip).
 int ovc_layer_norm_parts(const float* parts, int nparts, long part_stride, const float* bias, const float* residual,
                          const float* gamma, const float* beta, const uint8_t* zero_rows, float eps, float* y,
-                         int rows, int d, hipStream_t stream, const LazyRows& lazy = LazyRows{});
+                         int rows, int d, hipStream_t stream);
 const char* ovc_gemm_tiling_name(int tiling);        // kernel name as rocprofv3 prints it
 
 // ---- decode-time attention (attention.hip) -------------------------------------------------

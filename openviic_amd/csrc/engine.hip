@@ -106,7 +106,6 @@ struct Workspace {
     uint8_t* padflag;                             // [T][R]
     float* logits;                                // [R][V]
     float* stats;                                 // [R][blocks of 32 words, padded to even] float2: block maxima / sums of exponentials
-    float* lnst[2];                               // lazy LayerNorm: [R][d / 32] float2 block moments of the raw rows in x1 / x2
     float* running[2]; float* alive[2]; int32_t* hist[2]; float* lp[2]; int32_t* anc[2];
     int32_t* tok; float* cand_v; int32_t* cand_i; float* row_max; float* row_lsum; int32_t* order;
     float* all_buf;
@@ -169,7 +168,6 @@ Workspace carve(const ovc_model* m, void* base, int B, int N, int k, int return_
     w.padflag = a.take<uint8_t>(T * R);
     w.logits = a.take<float>(((R + 3) & ~(size_t)3) * (((size_t)m->vocab + 3) & ~(size_t)3));   // [R][V] or [V][R], rows padded to 16 bytes
     w.stats = a.take<float>(2 * ((((size_t)m->vocab + 31) / 32 + 1) & ~(size_t)1) * R);
-    w.lnst[0] = a.take<float>(2 * R * ((d + 31) / 32)); w.lnst[1] = a.take<float>(2 * R * ((d + 31) / 32));
     for (int i = 0; i < 2; ++i) {
         w.running[i] = a.take<float>(R); w.alive[i] = a.take<float>(R);
         w.hist[i] = a.take<int32_t>(R * T); w.lp[i] = a.take<float>(R * T); w.anc[i] = a.take<int32_t>(R * T);
@@ -249,17 +247,6 @@ int decode_ksplit(int K) {
     return s;
 }
 
-// Lazy LayerNorm applies to a decoder layer when the host supplied the folds (fp32 mode), the layer has no AoA gates (they read
-// the normalised rows) and the widths are whole 32-column blocks with a K-split second FFN product.  Without folds every
-// AddNorm is one LayerNorm kernel (the host's A/B switch: CaptionEngine.lazy_layer_norm / OVC_EAGER_LAYER_NORM).
-bool lazy_layer_norm(const ovc_model* m, const ovc_dec_layer& dl) {
-    if (m->precision != 0 || m->dec_kind != OVC_DEC_PLAIN || (m->d_model & 31)) return false;
-    if (dl.self_att.aoa_i.w || dl.cross_att.aoa_i.w || !dl.ffn.fc2.b || !dl.self_att.o.b || !dl.cross_att.o.b) return false;
-    const int split = decode_ksplit(m->d_ff);
-    if (split != 2 && split != 4) return false;
-    return dl.cross_q_fold.w && dl.cross_q_fold.u && dl.cross_q_fold.c && dl.ffn_fold.w && dl.ffn_fold.u && dl.ffn_fold.c;
-}
-
 using GemmShape = std::array<int, 7>;               // M, seg_n, nseg, K, kchains, ksplit, epilogue (0 plain, 1 stats, 2 stats_t)
 
 struct Engine {
@@ -323,28 +310,10 @@ struct Engine {
     // out = LayerNorm(x W^T + b + residual), rows flagged in zero_rows cleared.  With a partial-product buffer (the
     // M = B*k decode-step projections back to d_model) the GEMM runs as decode_ksplit(K) slices writing raw partial
     // products; the LayerNorm kernel sums them in slice order and applies bias and residual.
-    // One product of the lazy-LayerNorm chain (fp32 mode): y = act(x W^T + bias) + residual, where
-    //   * stats_out: leave the per-block moments of the finished rows (the LayerNorm they owe is applied by their readers);
-    //   * stats_in + fold_u / fold_c: x holds raw rows and W is the gamma-folded weight -- the row's mean / rstd enter in the epilogue;
-    //   * stats_in + res_ln: the residual rows are raw and normalised (res_ln's gamma / beta) as they are read.
-    int linear_lazy(const float* x, int K, const float* W, const float* bias, const float* residual, const ovc_norm* res_ln,
-                    const float* stats_in, float* y, float* stats_out, const float* fold_u, const float* fold_c, int M, int N, int act) {
-        GemmArgs a{};
-        a.A1 = x; a.lda1 = K; a.K1 = K; a.M = M; a.seg_n = N; a.nseg = 1; a.ldc = N;
-        a.R = residual; a.ldr = N; a.act = act;
-        a.seg[0] = GemmSegment{W, bias, y, nullptr, nullptr};
-        a.ln_out = stats_out;
-        a.ln_in = stats_in; a.ln_in_blocks = m->d_model / 32; a.ln_eps = m->ln_eps;
-        a.fold_u = fold_u; a.fold_c = fold_c;
-        if (res_ln) { a.res_g = res_ln->g; a.res_b = res_ln->b; }
-        return gemm(a);
-    }
-
     int linear_ln(const float* x, int K, const ovc_lin& l, const float* residual, const ovc_norm& ln,
-                  const uint8_t* zero_rows, float* y_tmp, float* part, float* out, int M, const LazyRows& lazy_res = LazyRows{}) {
+                  const uint8_t* zero_rows, float* y_tmp, float* part, float* out, int M) {
         const int d = m->d_model;
         const int split = part && l.b && residual ? decode_ksplit(K) : 1;
-        if (lazy_res.stats && split != 2 && split != 4) return OVC_EINVAL;       // the lazy chain needs the K-split consumer kernel
         if (split != 2 && split != 4) {
             TRY(linear(x, K, l, residual, y_tmp, M, d, 0));
             if (dry) return OVC_OK;
@@ -357,7 +326,7 @@ struct Engine {
         TRY(gemm(a));
         if (dry) return OVC_OK;
         if (!(debug_skip() & 1))
-            TRY(ovc_layer_norm_parts(part, split, a.part_stride, l.b, residual, ln.g, ln.b, zero_rows, m->ln_eps, out, M, d, stream, lazy_res));
+            TRY(ovc_layer_norm_parts(part, split, a.part_stride, l.b, residual, ln.g, ln.b, zero_rows, m->ln_eps, out, M, d, stream));
         for (int i = 0; i < extra_launches(); ++i) hipLaunchKernelGGL(noop_kernel, dim3(1), dim3(64), 0, stream);
         return OVC_OK;
     }
@@ -502,7 +471,6 @@ int run_decode_step(Engine& e, Workspace& w, int B, int N, int k, int t, int ret
     float* x = w.x;
     for (int l = 0; l < m->n_dec; ++l) {
         const ovc_dec_layer& dl = m->dec[l];
-        const bool lazy = lazy_layer_norm(m, dl);
         // ---- masked self-attention over the beam's own history ------------------------------------
         float* kc = w.kc + (size_t)l * T * R * hk;
         float* vc = w.vc + (size_t)l * T * R * hv;
@@ -517,21 +485,11 @@ int run_decode_step(Engine& e, Workspace& w, int B, int N, int k, int t, int ret
         sa.anc = w.anc[cur]; sa.anc_ld = T; sa.padflag = w.padflag; sa.pad_ld = R; sa.t = t; sa.width = width;
         sa.h = m->heads; sa.dk = m->d_k; sa.dv = m->d_v; sa.out = w.att; sa.ldo = hv;
         if (!(debug_skip() & 2)) RUN(ovc_decode_self_attention(sa, rows, s));
-        if (lazy) {
-            // Lazy LayerNorm (GemmArgs::ln_out, common.h): the two attention AddNorms of the layer are never materialised.  The
-            // output projections leave raw rows y1 / y2 (bias and residual applied) plus per-block moments; the products that
-            // read LayerNorm(y) take it through the host's gamma-folded weights (ovc_fold) and the row's mean / rstd in their
-            // epilogue, the residual paths normalise as they read.  Two launches per layer fewer, and nothing waits on a
-            // LayerNorm kernel whose whole cost was its launch.
-            TRY(e.linear_lazy(w.att, hv, dl.self_att.o.w, dl.self_att.o.b, x, nullptr, nullptr, w.x1, w.lnst[0], nullptr, nullptr, rows, d, 0));
-            TRY(e.linear_lazy(w.x1, d, dl.cross_q_fold.w, nullptr, nullptr, nullptr, w.lnst[0], w.q, nullptr, dl.cross_q_fold.u, dl.cross_q_fold.c, rows, hk, 0));
-        } else {
-            TRY(e.linear_ln(w.att, hv, dl.self_att.o, x, dl.self_att.ln, nullptr, w.y, w.part, w.x1, rows));
-            TRY(e.aoa(dl.self_att, x, w.x1, w.info, w.gate, rows));
-            TRY(e.linear(w.x1, d, dl.cross_att.q, nullptr, w.q, rows, hk, 0));
-        }
+        TRY(e.linear_ln(w.att, hv, dl.self_att.o, x, dl.self_att.ln, nullptr, w.y, w.part, w.x1, rows));
+        TRY(e.aoa(dl.self_att, x, w.x1, w.info, w.gate, rows));
 
         // ---- cross-attention: the image's beams share its projected encoder keys/values -----------
+        TRY(e.linear(w.x1, d, dl.cross_att.q, nullptr, w.q, rows, hk, 0));
         DecodeCrossArgs ca{};
         ca.q = w.q; ca.ldq = hk;
         ca.kx = w.kx + (size_t)l * lv * B * N * hk; ca.vx = w.vx + (size_t)l * lv * B * N * hv;
@@ -577,15 +535,6 @@ int run_decode_step(Engine& e, Workspace& w, int B, int N, int k, int t, int ret
             }
             RUN(ovc_meshed_mix(w.alpha, w.enc_att, lv, (long)nrd, sqrtf((float)lv), w.mixed, s));
             ffn_in = w.mixed;
-        } else if (lazy) {
-            // y2 = att W_o^T + b + LayerNorm_1(y1) (the residual normalised as it is read); FFN: relu(LayerNorm_2(y2) W_1^T + b_1)
-            // through the fold, then the K-split second product whose LayerNorm kernel adds the residual LayerNorm_2(y2)
-            TRY(e.linear_lazy(w.att, hv, dl.cross_att.o.w, dl.cross_att.o.b, w.x1, &dl.self_att.ln, w.lnst[0], w.x2, w.lnst[1], nullptr, nullptr, rows, d, 0));
-            TRY(e.linear_lazy(w.x2, d, dl.ffn_fold.w, nullptr, nullptr, nullptr, w.lnst[1], w.ff, nullptr, dl.ffn_fold.u, dl.ffn_fold.c, rows, m->d_ff, 1));
-            LazyRows lr; lr.stats = w.lnst[1]; lr.blocks = d / 32; lr.g = dl.cross_att.ln.g; lr.b = dl.cross_att.ln.b;
-            TRY(e.linear_ln(w.ff, m->d_ff, dl.ffn.fc2, w.x2, dl.ffn.ln, padflag_t, w.y, w.part, w.x, rows, lr));
-            x = w.x;
-            continue;
         } else {
             TRY(e.linear_ln(w.att, hv, dl.cross_att.o, w.x1, dl.cross_att.ln, nullptr, w.y, w.part, w.x2, rows));
             TRY(e.aoa(dl.cross_att, w.x1, w.x2, w.info, w.gate, rows));
@@ -669,7 +618,7 @@ int run_decode_step(Engine& e, Workspace& w, int B, int N, int k, int t, int ret
 
 }  // namespace
 
-extern "C" int ovc_abi_version(void) { return 7; }
+extern "C" int ovc_abi_version(void) { return 6; }
 
 extern "C" const char* ovc_build_info(void) {
     return "libovc gfx950 (CDNA4) fp32: v_mfma_f32_32x32x2_f32 GEMM + attention, HIP " __DATE__;

@@ -124,18 +124,12 @@ __device__ __forceinline__ void tile_coords(int tiles_m, int group_m, int xcd_pm
 
 // Epilogue of a wave's TM x TN accumulator tiles: + bias, activation, + residual, store (or, K-split, the raw partial product
 // of slice blockIdx.y).  D layout of a 32x32 tile: col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).  Branch-free on buffer
-// descriptors: one per-lane byte offset (first row of the lane's registers, its column) and a scalar row offset per accumulator
+// descriptors: one per-lane byte offset (first row of the lane's 16, its column) and a scalar row offset per accumulator
 // register; rows past M fall outside the descriptor and are dropped by the hardware, columns past seg_n get an
 // out-of-range offset.  (m0, n0) = first row / column of the wave's tiles.
-// A wave may hold only NR of a tile's 16 registers (the tilings whose K chains are spread over WK waves share the epilogue:
-// wave wk owns registers [wk * NR, (wk + 1) * NR), NR = 16 / WK): register r of its array then is tile row
-// (r&3) + 8*(r>>2) + row_base + 4*(lane>>5), row_base = 2 * NR * wk.
-// Lazy LayerNorm (GemmArgs::ln_in): lnrow = (mean, rstd) of the wave's rows, in LDS.
-template <int TM, int TN, int NR>
-__device__ __forceinline__ void store_wave_tiles(const GemmArgs& p, int seg, const float (&acc)[TM][TN][NR], int m0, int n0, int lane,
-                                                 int row_base = 0, const float* lnrow = nullptr) {
+template <int TM, int TN>
+__device__ __forceinline__ void store_wave_tiles(const GemmArgs& p, int seg, const f32x16 (&acc)[TM][TN], int m0, int n0, int lane) {
     const float* __restrict__ bias = p.seg[seg].bias;
-    const bool folded = p.fold_u != nullptr, lazy_res = p.res_g != nullptr;   // uniform
     float* __restrict__ C = p.seg[seg].C + (size_t)blockIdx.y * p.part_stride;
     const int half = lane >> 5;
     const bool has_res = p.R != nullptr;                          // uniform
@@ -143,81 +137,41 @@ __device__ __forceinline__ void store_wave_tiles(const GemmArgs& p, int seg, con
     const __amdgpu_buffer_rsrc_t rsrc_r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(has_res ? p.R : p.A1), 0,
                                                                              has_res && p.res_mod == 0 ? p.M * p.ldr * 4 : 0, 0x00020000);
     constexpr int kOutOfRange = 0x7ffffff0;
-    auto row_of = [](int r) { return (r & 3) + 8 * (r >> 2); };    // register -> tile row (before row_base and the lane half)
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int n = n0 + j * 32 + (lane & 31);
         const bool n_ok = n < p.seg_n;
-        const int nc = min(n, p.seg_n - 1);
-        const float bv = folded ? p.fold_c[nc] : (bias ? bias[nc] : 0.f);
-        const float uv = folded ? p.fold_u[nc] : 0.f;
-        const float rg = lazy_res ? p.res_g[nc] : 0.f, rb = lazy_res ? p.res_b[nc] : 0.f;
+        const float bv = bias ? bias[min(n, p.seg_n - 1)] : 0.f;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
-            const int mbase = m0 + i * 32 + 4 * half + row_base;
-            float out[NR];
-            // (mean, rstd) of register r's row: re-read from LDS at each use rather than held (the 32x32 tilings have no
-            // registers to spare under their five-waves cap)
-            const float* lnr = lnrow + 2 * (i * 32 + 4 * half + row_base);
+            const int mbase = m0 + i * 32 + 4 * half;
+            float out[16];
 #pragma unroll
-            for (int r = 0; r < NR; ++r) {
-                float v = acc[i][j][r];
-                if (folded) {
-                    const f32x2 mr = *reinterpret_cast<const f32x2*>(lnr + 2 * row_of(r));
-                    v = mr[1] * (v - mr[0] * uv);
-                }
-                v += bv;
+            for (int r = 0; r < 16; ++r) {
+                const float v = acc[i][j][r] + bv;
                 out[r] = p.act == 1 ? fmaxf(v, 0.f) : v;
             }
             if (has_res) {
-                float res[NR];
+                float res[16];
                 if (p.res_mod == 0) {
                     const int voff_r = n_ok ? (mbase * p.ldr + n) * 4 : kOutOfRange;
 #pragma unroll
-                    for (int r = 0; r < NR; ++r)
-                        res[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc_r, voff_r, row_of(r) * p.ldr * 4, 0));
+                    for (int r = 0; r < 16; ++r)
+                        res[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc_r, voff_r, ((r & 3) + 8 * (r >> 2)) * p.ldr * 4, 0));
                 } else {                                           // residual broadcast over stacked row blocks
 #pragma unroll
-                    for (int r = 0; r < NR; ++r) {
-                        const int mc = min(mbase + row_of(r), p.M - 1) % p.res_mod;
+                    for (int r = 0; r < 16; ++r) {
+                        const int mc = min(mbase + (r & 3) + 8 * (r >> 2), p.M - 1) % p.res_mod;
                         res[r] = p.R[(size_t)mc * p.ldr + min(n, p.seg_n - 1)];
                     }
                 }
-                if (lazy_res) {                                    // the residual rows still owe their LayerNorm
 #pragma unroll
-                    for (int r = 0; r < NR; ++r) {
-                        const f32x2 mr = *reinterpret_cast<const f32x2*>(lnr + 2 * row_of(r));
-                        res[r] = (res[r] - mr[0]) * mr[1] * rg + rb;
-                    }
-                }
-#pragma unroll
-                for (int r = 0; r < NR; ++r) out[r] += res[r];
+                for (int r = 0; r < 16; ++r) out[r] += res[r];
             }
             const int voff_c = n_ok ? (mbase * p.ldc + n) * 4 : kOutOfRange;
 #pragma unroll
-            for (int r = 0; r < NR; ++r)
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, out[r]), rsrc_c, voff_c, row_of(r) * p.ldc * 4, 0);
-            if (p.ln_out) {
-                // Producer side of the lazy LayerNorm: per output row and 32-column block the sum and the sum of squared
-                // deviations from the block mean -- two half-wave reductions per register, blocks are the global 32-column
-                // blocks and the order is fixed, so every tiling leaves the same bits.  Lane l < NR of a half keeps register
-                // l's pair; one store writes the wave's (row, block) entries of the tile.
-                float bs = 0.f, bq = 0.f;
-#pragma unroll
-                for (int r = 0; r < NR; ++r) {
-                    const float sum = half_wave_sum(out[r]);
-                    const float dev = out[r] - sum * (1.f / 32.f);
-                    float sq = dev * dev;
-                    asm volatile("" : "+v"(sq));       // a rounded product in every lane: contracted into the reduction's first add
-                                                       // (fma) it would stay unrounded on one side of each lane pair
-                    const float m2 = half_wave_sum(sq);
-                    if ((lane & 31) == r) { bs = sum; bq = m2; }
-                }
-                const int rr = lane & 31, row = mbase + row_of(rr);
-                if (rr < NR && row < p.M && n0 + j * 32 < p.seg_n)
-                    *reinterpret_cast<f32x2*>(p.ln_out + 2 * ((size_t)row * (p.seg_n >> 5) + ((n0 + j * 32) >> 5))) = f32x2{bs, bq};
-            }
-            if constexpr (NR == 16) {
+            for (int r = 0; r < 16; ++r)
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, out[r]), rsrc_c, voff_c, ((r & 3) + 8 * (r >> 2)) * p.ldc * 4, 0);
             if (p.stats_t) {
                 // Transposed vocabulary product: this lane's 16 registers are 16 words (rows) of ONE beam row (column n), and the
                 // lane 32 further on holds the block's other 16.  Block maximum and sum exp(y - maximum) are in-register
@@ -229,7 +183,7 @@ __device__ __forceinline__ void store_wave_tiles(const GemmArgs& p, int seg, con
                 float bm = -INFINITY;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    v[r] = mrow + row_of(r) < p.M ? out[r] : -INFINITY;
+                    v[r] = mrow + (r & 3) + 8 * (r >> 2) < p.M ? out[r] : -INFINITY;
                     bm = fmaxf(bm, v[r]);
                 }
                 float x, y;
@@ -258,27 +212,12 @@ __device__ __forceinline__ void store_wave_tiles(const GemmArgs& p, int seg, con
                     const float sum = half_wave_sum(__expf(v - m));
                     if ((lane & 15) == r) { bm = m; bs = sum; }
                 }
-                const int rr = lane & 15, row = mbase + row_of(rr);
+                const int rr = lane & 15, row = mbase + (rr & 3) + 8 * (rr >> 2);
                 if ((lane & 31) < 16 && row < p.M && n0 + j * 32 < p.seg_n)
                     *reinterpret_cast<f32x2*>(p.stats + 2 * ((size_t)row * p.stats_ld + ((n0 + j * 32) >> 5))) = f32x2{bm, bs};
             }
-            }
         }
     }
-}
-
-// the whole-tile form: a wave that holds all 16 registers of its tiles
-template <int TM, int TN>
-__device__ __forceinline__ void store_wave_tiles(const GemmArgs& p, int seg, const f32x16 (&acc)[TM][TN], int m0, int n0, int lane,
-                                                 const float* lnrow = nullptr) {
-    float full[TM][TN][16];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) full[i][j][r] = acc[i][j][r];
-    store_wave_tiles<TM, TN, 16>(p, seg, full, m0, n0, lane, 0, lnrow);
 }
 
 #include "gemm_split.h"   // gemm_split_mfma: the opt-in split-precision classes (bf16 planes on the 16-bit matrix path)
@@ -295,7 +234,6 @@ __global__ __launch_bounds__(256, (min_waves_per_simd<BM, BN, BK, NC>())) void g
     constexpr int kVecPerRow = BK / 4;               // float4 per tile row
     constexpr int kRowsPerPass = 256 / kVecPerRow;   // tile rows covered by one pass of the 256 loader threads
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    __shared__ float lnrow[2 * BM];                  // lazy LayerNorm: (mean, rstd) of the workgroup's rows
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -416,17 +354,6 @@ __global__ __launch_bounds__(256, (min_waves_per_simd<BM, BN, BK, NC>())) void g
                 for (int r = 0; r < 16; ++r) acc[c][i][j][r] = 0.f;
 
     load_tile(0);
-    // Lazy LayerNorm: (mean, rstd) of this workgroup's rows from the producer's per-block (sum, M2) pairs, in block order
-    // (Chan's combination).  Issued behind the first tile's loads (its
-    // latency overlaps theirs), read by the epilogue many barriers later.
-    if (p.ln_in && tid < BM) {
-        float mean, rstd;
-        ovc_ln_row_moments(reinterpret_cast<const f32x2*>(p.ln_in) + (size_t)min(m0 + tid, p.M - 1) * p.ln_in_blocks, p.ln_in_blocks,
-                           p.ln_eps, mean, rstd);
-        lnrow[2 * tid] = mean;
-        lnrow[2 * tid + 1] = rstd;
-    }
-
     store_tile(0);
     __syncthreads();
 
@@ -488,12 +415,8 @@ __global__ __launch_bounds__(256, (min_waves_per_simd<BM, BN, BK, NC>())) void g
     }
 
     // Chain reduction, always in chain order ((c0 + c1) + c2) + c3 whatever the wave layout: chain c lives in wave
-    // c % WK, accumulator set c / WK.  With the chains spread over WK > 1 waves the EPILOGUE is spread too: wave wk owns
-    // registers [wk * NR, (wk + 1) * NR) of every tile (NR = 16 / WK), the waves park what they do not own in LDS (the tile
-    // buffers are free after the last barrier), and every wave adds up and stores its rows -- a quarter of the LDS reads,
-    // residual loads and stores per wave instead of all of them on wave 0 while three waves have already left.
-    const int m0w = m0 + wm * Cfg::kWaveM, n0w = n0 + wn * Cfg::kWaveN;
-#ifdef OVC_WAVE0_EPILOGUE
+    // c % WK, accumulator set c / WK.  Waves wk > 0 park their sets in LDS (the tile buffers are free after the last
+    // barrier), wave wk == 0 adds everything up and runs the epilogue.
     if (Cfg::kChains > 1) {
         float* red = lds;
         const int wtile = wm * WN + wn;
@@ -517,7 +440,7 @@ __global__ __launch_bounds__(256, (min_waves_per_simd<BM, BN, BK, NC>())) void g
 #pragma unroll
         for (int chain = 1; chain < Cfg::kChains; ++chain) {
             constexpr int kW = WK;
-            const int w = chain % kW, c = chain / kW;
+            const int w = chain % kW, c = chain / kW;          // compile-time after unrolling
 #pragma unroll
             for (int i = 0; i < Cfg::TM; ++i)
 #pragma unroll
@@ -527,63 +450,8 @@ __global__ __launch_bounds__(256, (min_waves_per_simd<BM, BN, BK, NC>())) void g
                         acc[0][i][j][r] += w == 0 ? acc[c][i][j][r] : red[red_index(w, c, i, j, r)];
         }
     }
-    store_wave_tiles<Cfg::TM, Cfg::TN>(p, seg, acc[0], m0w, n0w, lane, lnrow + 2 * wm * Cfg::kWaveM);
-    return;
-#endif
-    if constexpr (WK > 1) {
-        constexpr int NR = 16 / WK;
-        float* red = lds;
-        const int wtile = wm * WN + wn;
-        // slot of (source wave w, owner o != w, set c, tile, register rr of the owner's NR)
-        auto red_index = [&](int w, int o, int c, int i, int j, int rr) {
-            const int src = w < o ? w : w - 1;
-            return (((((((o * (WK - 1) + src) * NC + c) * (WM * WN) + wtile) * Cfg::TM + i) * Cfg::TN + j) * NR + rr) * 64) + lane;
-        };
-#pragma unroll
-        for (int o = 0; o < WK; ++o) {
-            if (o == wk) continue;                                // uniform
-#pragma unroll
-            for (int c = 0; c < NC; ++c)
-#pragma unroll
-                for (int i = 0; i < Cfg::TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < Cfg::TN; ++j)
-#pragma unroll
-                        for (int rr = 0; rr < NR; ++rr) red[red_index(wk, o, c, i, j, rr)] = acc[c][i][j][o * NR + rr];
-        }
-        __syncthreads();
-        float own[Cfg::TM][Cfg::TN][NR];
-#pragma unroll
-        for (int o = 0; o < WK; ++o) {
-            if (o != wk) continue;                                // uniform: the copy of this loop body whose indices are mine
-#pragma unroll
-            for (int i = 0; i < Cfg::TM; ++i)
-#pragma unroll
-                for (int j = 0; j < Cfg::TN; ++j)
-#pragma unroll
-                    for (int rr = 0; rr < NR; ++rr) {
-                        float total = 0.f;
-#pragma unroll
-                        for (int chain = 0; chain < Cfg::kChains; ++chain) {
-                            const int w = chain % WK, c = chain / WK;          // compile-time after unrolling
-                            const float v = w == o ? acc[c][i][j][o * NR + rr] : red[red_index(w, o, c, i, j, rr)];
-                            total = chain == 0 ? v : total + v;
-                        }
-                        own[i][j][rr] = total;
-                    }
-        }
-        store_wave_tiles<Cfg::TM, Cfg::TN, NR>(p, seg, own, m0w, n0w, lane, 2 * NR * wk, lnrow + 2 * wm * Cfg::kWaveM);
-    } else {
-#pragma unroll
-        for (int c = 1; c < NC; ++c)                               // one wave holds every chain: sets in chain order
-#pragma unroll
-            for (int i = 0; i < Cfg::TM; ++i)
-#pragma unroll
-                for (int j = 0; j < Cfg::TN; ++j)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[0][i][j][r] += acc[c][i][j][r];
-        store_wave_tiles<Cfg::TM, Cfg::TN>(p, seg, acc[0], m0w, n0w, lane, lnrow + 2 * wm * Cfg::kWaveM);
-    }
+
+    store_wave_tiles<Cfg::TM, Cfg::TN>(p, seg, acc[0], m0 + wm * Cfg::kWaveM, n0 + wn * Cfg::kWaveN, lane);
 }
 
 // tile order shared by both kernels: super-rows of M tiles when the A panel exceeds an L2, else the 2-D XCD split with
@@ -843,15 +711,6 @@ int ovc_gemm_launch(const GemmArgs& a, hipStream_t stream, const GemmLaunchOpts&
     if (a.zero_rows_out && (a.K2 || a.ksplit > 1 || a.kchains > kSplitClass)) return OVC_EINVAL;
     if (a.stats && (a.nseg != 1 || a.ksplit > 1 || !ovc_aligned16(a.stats) || a.stats_ld < (a.seg_n + 31) / 32)) return OVC_EINVAL;
     if (a.stats_t && (a.stats || a.seg[0].bias || a.nseg != 1 || a.ksplit > 1 || !ovc_aligned16(a.stats_t) || a.stats_ld < (a.M + 31) / 32)) return OVC_EINVAL;
-    // lazy LayerNorm: fp32 classes only, one segment, no K split, whole 32-column blocks
-    if (a.ln_out || a.ln_in || a.fold_u || a.fold_c || a.res_g || a.res_b) {
-        if (a.kchains > kSplitClass || a.nseg != 1 || a.ksplit > 1 || a.res_mod) return OVC_EINVAL;
-        if (a.ln_out && ((a.seg_n & 31) || !ovc_aligned16(a.ln_out))) return OVC_EINVAL;
-        if ((a.fold_u != nullptr) != (a.fold_c != nullptr) || (a.res_g != nullptr) != (a.res_b != nullptr)) return OVC_EINVAL;
-        if ((a.fold_u || a.res_g) && (!a.ln_in || a.ln_in_blocks <= 0 || !ovc_aligned16(a.ln_in) || !(a.ln_eps > 0.f))) return OVC_EINVAL;
-        if (a.ln_in && !a.fold_u && !a.res_g) return OVC_EINVAL;
-        if (a.res_g && !a.R) return OVC_EINVAL;
-    }
     if (a.K2 > 0 && (a.K1 % 32)) return OVC_EINVAL;      // the A1|A2 seam must fall on a K-tile boundary
     if (a.ksplit > 1) {                                  // raw partial products: see GemmArgs::ksplit
         if (a.ksplit > kMaxKSplit || a.nseg != 1 || a.K2 || a.R || a.act || a.seg[0].bias) return OVC_EINVAL;
@@ -1061,25 +920,6 @@ extern "C" int ovc_debug_linear_tiling(const float* x, int K, const float* W, co
         if (rc != OVC_OK) return rc;
     }
     return OVC_OK;
-}
-
-// The lazy-LayerNorm arguments of one product (GemmArgs::ln_out / ln_in / fold_* / res_*, common.h) by one named tiling:
-// y = act(x W^T + bias) + residual with, each optional, the row moments written (stats_out), x taken through a fold
-// (fold_u / fold_c + stats_in) and the residual rows normalised as they are read (res_g / res_b + stats_in).
-extern "C" int ovc_debug_lazy_linear(const float* x, int K, const float* W, const float* bias, const float* residual,
-                                     const float* res_g, const float* res_b, const float* stats_in, int in_blocks,
-                                     const float* fold_u, const float* fold_c, float eps, float* y, float* stats_out,
-                                     int M, int N, int act, int tiling, ovc_stream stream) {
-    if (tiling < 0 || tiling >= kNumTilings || !x || !W || !y) return OVC_EINVAL;
-    GemmArgs a{};
-    a.A1 = x; a.lda1 = K; a.K1 = K; a.M = M; a.seg_n = N; a.nseg = 1; a.ldc = N; a.kchains = tiling_chains(tiling);
-    a.R = residual; a.ldr = N; a.act = act;
-    a.seg[0] = GemmSegment{W, bias, y, nullptr};
-    a.ln_out = stats_out; a.ln_in = stats_in; a.ln_in_blocks = in_blocks; a.ln_eps = eps;
-    a.fold_u = fold_u; a.fold_c = fold_c; a.res_g = res_g; a.res_b = res_b;
-    GemmLaunchOpts opts{};
-    opts.forced_tiling = tiling;
-    return ovc_gemm_launch(a, ovc_hip_stream(stream), opts);
 }
 
 extern "C" int ovc_linear(const float* x, int ldx, const float* x2, int ldx2, int K1, int K2,

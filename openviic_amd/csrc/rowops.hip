@@ -15,16 +15,12 @@ namespace {
 // Everything a row needs (slices, bias, residual) is loaded before the first use: the operand set is a
 // template parameter, because hipcc turns every run-time "load or skip" into a branch with a full
 // s_waitcnt, which serialised the 3..6 loads of a row into as many memory round trips.
-//
-// kLazy: the residual rows still owe their own LayerNorm (GemmArgs::ln_out, common.h): `lazy` brings their per-block
-// moments and that LayerNorm's gamma / beta, and the residual is normalised as it is read.
 // ---------------------------------------------------------------------------------------------
 constexpr int kMaxVec = 8;   // float4 per lane -> d <= 2048
 
-template <int kVecs, int kParts, bool kBias, bool kRes, bool kLazy>
+template <int kVecs, int kParts, bool kBias, bool kRes>
 __global__ __launch_bounds__(256) void layer_norm_rows(const float* __restrict__ x, long part_stride,
                                                        const float* __restrict__ bias, const float* __restrict__ residual,
-                                                       LazyRows lazy,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        const float* __restrict__ add, int add_rows,
                                                        const uint8_t* __restrict__ zero_rows, float eps,
@@ -61,23 +57,9 @@ __global__ __launch_bounds__(256) void layer_norm_rows(const float* __restrict__
         gv[i] = reinterpret_cast<const f32x4*>(gamma)[col[i]];
         bev[i] = reinterpret_cast<const f32x4*>(beta)[col[i]];
     }
-    f32x4 lg[kVecs], lb[kVecs];
-    if (kLazy) {
-#pragma unroll
-        for (int i = 0; i < kVecs; ++i) {
-            lg[i] = reinterpret_cast<const f32x4*>(lazy.g)[col[i]];
-            lb[i] = reinterpret_cast<const f32x4*>(lazy.b)[col[i]];
-        }
-    }
     if (cleared) {
         for (int c = lane; c < nvec; c += 64) reinterpret_cast<f32x4*>(yrow)[c] = f32x4{0.f, 0.f, 0.f, 0.f};
         return;
-    }
-    if (kLazy) {
-        float rmean, rrstd;      // every lane walks the row's pairs (same addresses: broadcast loads) in the producer's block order
-        ovc_ln_row_moments(reinterpret_cast<const f32x2*>(lazy.stats) + (size_t)row * lazy.blocks, lazy.blocks, eps, rmean, rrstd);
-#pragma unroll
-        for (int i = 0; i < kVecs; ++i) rv[i] = (rv[i] - rmean) * rrstd * lg[i] + lb[i];
     }
     f32x4 v[kVecs];
     float sum = 0.f;
@@ -112,45 +94,18 @@ __global__ __launch_bounds__(256) void layer_norm_rows(const float* __restrict__
     }
 }
 
-template <int kParts, bool kBias, bool kRes, bool kLazy = false>
-int launch_layer_norm(const float* x, long part_stride, const float* bias, const float* residual, LazyRows lazy, const float* gamma,
+template <int kParts, bool kBias, bool kRes>
+int launch_layer_norm(const float* x, long part_stride, const float* bias, const float* residual, const float* gamma,
                       const float* beta, const float* add, int add_rows, const uint8_t* zero_rows, float eps, float* y,
                       int rows, int d, hipStream_t stream) {
     const int vecs = ((d >> 2) + 63) / 64;
     const dim3 grid((rows + 3) / 4), block(256);
-#define OVC_LN(V) hipLaunchKernelGGL((layer_norm_rows<V, kParts, kBias, kRes, kLazy>), grid, block, 0, stream, x, part_stride, bias, \
-                                     residual, lazy, gamma, beta, add, add_rows, zero_rows, eps, y, rows, d)
+#define OVC_LN(V) hipLaunchKernelGGL((layer_norm_rows<V, kParts, kBias, kRes>), grid, block, 0, stream, x, part_stride, bias, \
+                                     residual, gamma, beta, add, add_rows, zero_rows, eps, y, rows, d)
     if (vecs <= 1) OVC_LN(1); else if (vecs <= 2) OVC_LN(2); else if (vecs <= 4) OVC_LN(4); else OVC_LN(8);
 #undef OVC_LN
     OVC_RETURN_IF_LAUNCH_FAILED();
     return OVC_OK;
-}
-
-// Lazy-LayerNorm fold of a projection (ovc_fold, include/ovc.h): one wave per output row n.  u sums the ROUNDED folded weights
-// (the values the product multiplies by) and both sums run in double, so the fold adds one fp32 rounding per element, not K.
-__global__ __launch_bounds__(256) void fold_weight_kernel(const float* __restrict__ W, const float* __restrict__ bias,
-                                                          const float* __restrict__ gamma, const float* __restrict__ beta, int N, int K,
-                                                          float* __restrict__ w_out, float* __restrict__ u_out, float* __restrict__ c_out) {
-    const int lane = threadIdx.x & 63;
-    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (n >= N) return;
-    double u = 0.0, c = 0.0;
-    for (int k = lane; k < K; k += 64) {
-        const float wv = W[(size_t)n * K + k];
-        const float folded = wv * gamma[k];
-        w_out[(size_t)n * K + k] = folded;
-        u += (double)folded;
-        c += (double)wv * (double)beta[k];
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        u += __shfl_xor(u, off, 64);
-        c += __shfl_xor(c, off, 64);
-    }
-    if (lane == 0) {
-        u_out[n] = (float)u;
-        c_out[n] = (float)(c + (bias ? (double)bias[n] : 0.0));
-    }
 }
 
 // mask[r] = (sum_f x[r,f] == 0): one wave per row, 16-byte coalesced loads.
@@ -324,33 +279,18 @@ extern "C" int ovc_layer_norm(const float* x, const float* residual, const float
     if (!ovc_aligned16(x) || !ovc_aligned16(y) || !ovc_aligned16(gamma) || !ovc_aligned16(beta) ||
         (residual && !ovc_aligned16(residual)) || (add && !ovc_aligned16(add))) return OVC_EINVAL;
     hipStream_t s = ovc_hip_stream(stream);
-    return residual ? launch_layer_norm<1, false, true>(x, 0L, nullptr, residual, LazyRows{}, gamma, beta, add, add_rows, zero_rows, eps, y, rows, d, s)
-                    : launch_layer_norm<1, false, false>(x, 0L, nullptr, nullptr, LazyRows{}, gamma, beta, add, add_rows, zero_rows, eps, y, rows, d, s);
+    return residual ? launch_layer_norm<1, false, true>(x, 0L, nullptr, residual, gamma, beta, add, add_rows, zero_rows, eps, y, rows, d, s)
+                    : launch_layer_norm<1, false, false>(x, 0L, nullptr, nullptr, gamma, beta, add, add_rows, zero_rows, eps, y, rows, d, s);
 }
 
 int ovc_layer_norm_parts(const float* parts, int nparts, long part_stride, const float* bias, const float* residual,
                          const float* gamma, const float* beta, const uint8_t* zero_rows, float eps, float* y,
-                         int rows, int d, hipStream_t stream, const LazyRows& lazy) {
+                         int rows, int d, hipStream_t stream) {
     if (!parts || !bias || !residual || !gamma || !beta || !y || rows <= 0 || d <= 0 || (d & 3) || d > 64 * 4 * kMaxVec) return OVC_EINVAL;
     if ((part_stride & 3) || !ovc_aligned16(parts) || !ovc_aligned16(y) || !ovc_aligned16(bias) || !ovc_aligned16(residual)) return OVC_EINVAL;
-    if (lazy.stats) {
-        if (!lazy.g || !lazy.b || lazy.blocks * 32 != d || !ovc_aligned16(lazy.stats) || !ovc_aligned16(lazy.g) || !ovc_aligned16(lazy.b)) return OVC_EINVAL;
-        if (nparts == 2) return launch_layer_norm<2, true, true, true>(parts, part_stride, bias, residual, lazy, gamma, beta, nullptr, 0, zero_rows, eps, y, rows, d, stream);
-        if (nparts == 4) return launch_layer_norm<4, true, true, true>(parts, part_stride, bias, residual, lazy, gamma, beta, nullptr, 0, zero_rows, eps, y, rows, d, stream);
-        return OVC_EINVAL;
-    }
-    if (nparts == 2) return launch_layer_norm<2, true, true>(parts, part_stride, bias, residual, lazy, gamma, beta, nullptr, 0, zero_rows, eps, y, rows, d, stream);
-    if (nparts == 4) return launch_layer_norm<4, true, true>(parts, part_stride, bias, residual, lazy, gamma, beta, nullptr, 0, zero_rows, eps, y, rows, d, stream);
+    if (nparts == 2) return launch_layer_norm<2, true, true>(parts, part_stride, bias, residual, gamma, beta, nullptr, 0, zero_rows, eps, y, rows, d, stream);
+    if (nparts == 4) return launch_layer_norm<4, true, true>(parts, part_stride, bias, residual, gamma, beta, nullptr, 0, zero_rows, eps, y, rows, d, stream);
     return OVC_EINVAL;
-}
-
-extern "C" int ovc_fold_weight(const float* W, const float* bias, const float* gamma, const float* beta, int N, int K,
-                               float* w_out, float* u_out, float* c_out, ovc_stream stream) {
-    if (const int rc = ovc_device_guard()) return rc;
-    if (!W || !gamma || !beta || !w_out || !u_out || !c_out || N <= 0 || K <= 0 || (K & 3) || !ovc_aligned16(w_out)) return OVC_EINVAL;
-    hipLaunchKernelGGL(fold_weight_kernel, dim3((N + 3) / 4), dim3(256), 0, ovc_hip_stream(stream), W, bias, gamma, beta, N, K, w_out, u_out, c_out);
-    OVC_RETURN_IF_LAUNCH_FAILED();
-    return OVC_OK;
 }
 
 extern "C" int ovc_zero_row_mask(const float* x, int rows, int d, uint8_t* mask, ovc_stream stream) {

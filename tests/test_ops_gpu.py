@@ -452,76 +452,6 @@ def test_every_tiling_of_a_k_order_class_gives_the_same_bits(M, N, K):
         assert err[104] < 4 * err[1] and err[103] < 8 * err[1], err     # 22 / 24 operand bits: the fp32 path's own error level
 
 
-@pytest.mark.parametrize("M,d,N2,shift", [(80, 512, 2048, 0.0), (1280, 512, 512, 3.0), (37, 96, 64, -50.0), (130, 1088, 160, 0.5)])
-def test_lazy_layer_norm_chain_matches_the_materialised_layer_norm(M, d, N2, shift):
-    """The decode step's lazy LayerNorm (GemmArgs::ln_out / ln_in, engine.hip): a producer leaves raw rows y plus per
-    (row, 32-column block) moments; a consumer product reads LayerNorm(y) through the gamma-folded weight of ovc_fold_weight and
-    the row's mean / rstd in its epilogue, and a residual path normalises y as it reads it.  Against fp64 LayerNorm + products
-    (row means far from zero -- ``shift`` -- included: the moments are block-wise deviations, not E[x^2] - mean^2), for every
-    fp32 tiling, and bit for bit across the tilings of a class.  d = 1088 walks more than one batch of 16 blocks."""
-    from openviic_amd import native
-    lib = native.load()
-    lib.ovc_profile_kernel_name.restype = __import__("ctypes").c_char_p
-    g = torch.Generator().manual_seed(M + d + N2)
-    K1 = 64
-    x = torch.randn(M, K1, generator=g)
-    w_o, b_o = torch.randn(d, K1, generator=g) / math.sqrt(K1), torch.randn(d, generator=g)
-    res = torch.randn(M, d, generator=g) + shift
-    gamma, beta = 1 + 0.3 * torch.randn(d, generator=g), 0.2 * torch.randn(d, generator=g)
-    w2, b2 = torch.randn(N2, d, generator=g) / math.sqrt(d), torch.randn(N2, generator=g)
-    att = torch.randn(M, K1, generator=g)
-    eps = 1e-5
-    y64 = x.double() @ w_o.double().T + b_o.double() + res.double()
-    ln64 = torch.nn.functional.layer_norm(y64, (d,), gamma.double(), beta.double(), eps)
-    want2 = torch.relu(ln64 @ w2.double().T + b2.double())                     # consumer: relu(LayerNorm(y) W2^T + b2)
-    want3 = att.double() @ w_o.double().T + b_o.double() + ln64               # residual path: att W^T + b + LayerNorm(y)
-    xd, wod, bod, resd, gd, bed, w2d, b2d, attd = (t.to(DEV) for t in (x, w_o, b_o, res, gamma, beta, w2, b2, att))
-    fw, fu, fc = torch.empty(N2, d, device=DEV), torch.empty(N2, device=DEV), torch.empty(N2, device=DEV)
-    assert lib.ovc_fold_weight(w2d.data_ptr(), b2d.data_ptr(), gd.data_ptr(), bed.data_ptr(), N2, d, fw.data_ptr(), fu.data_ptr(),
-                               fc.data_ptr(), native.stream_handle()) == 0
-    np.testing.assert_allclose(fw.cpu().numpy(), (w2 * gamma).numpy(), rtol=0, atol=0)
-    np.testing.assert_allclose(fu.cpu().double().numpy(), (w2 * gamma).double().sum(1).numpy(), rtol=1e-6, atol=1e-6)
-    np.testing.assert_allclose(fc.cpu().double().numpy(), (w2.double() @ beta.double() + b2.double()).numpy(), rtol=1e-6, atol=1e-6)
-    nb = d // 32
-    first = {}
-    for t, name, chains in _tilings(lib):
-        if chains > 4:
-            continue
-        y, st = torch.empty(M, d, device=DEV), torch.full((M, nb, 2), float("nan"), device=DEV)
-        rc = lib.ovc_debug_lazy_linear(xd.data_ptr(), K1, wod.data_ptr(), bod.data_ptr(), resd.data_ptr(), None, None, None, 0, None, None,
-                                       eps, y.data_ptr(), st.data_ptr(), M, d, 0, t, native.stream_handle())
-        assert rc == 0, name
-        _close(y, y64, tol=2e-5, what=name + " producer rows")
-        blocks = y.cpu().double().view(M, nb, 32)
-        np.testing.assert_allclose(st[..., 0].cpu().double().numpy(), blocks.sum(-1).numpy(), rtol=1e-5, atol=1e-4, err_msg=name)
-        np.testing.assert_allclose(st[..., 1].cpu().double().numpy(), ((blocks - blocks.mean(-1, keepdim=True)) ** 2).sum(-1).numpy(),
-                                   rtol=1e-4, atol=1e-4, err_msg=name)
-        y2 = torch.empty(M, N2, device=DEV)
-        rc = lib.ovc_debug_lazy_linear(y.data_ptr(), d, fw.data_ptr(), None, None, None, None, st.data_ptr(), nb, fu.data_ptr(), fc.data_ptr(),
-                                       eps, y2.data_ptr(), None, M, N2, 1, t, native.stream_handle())
-        assert rc == 0, name
-        _close(y2, want2, tol=3e-5, what=name + " folded consumer")
-        y3, st3 = torch.empty(M, d, device=DEV), torch.empty(M, nb, 2, device=DEV)
-        rc = lib.ovc_debug_lazy_linear(attd.data_ptr(), K1, wod.data_ptr(), bod.data_ptr(), y.data_ptr(), gd.data_ptr(), bed.data_ptr(),
-                                       st.data_ptr(), nb, None, None, eps, y3.data_ptr(), st3.data_ptr(), M, d, 0, t, native.stream_handle())
-        assert rc == 0, name
-        _close(y3, want3, tol=3e-5, what=name + " lazily normalised residual")
-        got = (y, st, y2, y3, st3)
-        if chains in first:
-            for a, b in zip(got, first[chains][1]):
-                assert torch.equal(a, b), "%s differs from %s (same K-order class)" % (name, first[chains][0])
-        else:
-            first[chains] = (name, got)
-    assert set(first) == {1, 4}
-    # argument checks: a fold without moments, moments without a reader, a split-precision tiling
-    bad = lib.ovc_debug_lazy_linear(xd.data_ptr(), K1, wod.data_ptr(), None, None, None, None, None, 0, fu.data_ptr(), fc.data_ptr(), eps,
-                                    y.data_ptr(), None, M, d, 0, 0, native.stream_handle())
-    assert bad == -1
-    split = [t for t, _, c in _tilings(lib) if c > 4][0]
-    assert lib.ovc_debug_lazy_linear(xd.data_ptr(), K1, wod.data_ptr(), bod.data_ptr(), None, None, None, None, 0, None, None, eps,
-                                     y.data_ptr(), st.data_ptr(), M, d, 0, split, native.stream_handle()) == -1
-
-
 @pytest.mark.parametrize("M,N,K,ksplit", [(130, 200, 96, 1), (65, 33, 48, 1), (1280, 512, 512, 2), (31, 10201, 64, 1), (640, 40, 2048, 4),
                                           (5, 64, 32, 1), (257, 1536, 128, 1)])
 def test_pre_cut_weight_planes_give_the_bits_of_cutting_in_the_kernel(M, N, K, ksplit):
