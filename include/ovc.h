@@ -154,20 +154,11 @@ typedef struct {
 } ovc_mha;
 
 typedef struct { ovc_lin fc1, fc2; ovc_norm ln; } ovc_ffn;
-/* Fold of a projection y = LayerNorm(x) W^T + b that lets the product absorb the LayerNorm (ovc_fold_weight builds it,
-   ovc_addnorm_linear uses it; fp32 mode, plain decoder layers without AoA gates; all NULL = every AddNorm runs as its own
-   LayerNorm kernel, same captions):
-     w[n,k] = W[n,k] * gamma[k],   u[n] = sum_k w[n,k],   c[n] = sum_k W[n,k] * beta[k] + b[n]
-   so that  y = rstd * (x w^T - mean * u) + c  with the row's mean / rstd applied in the product's epilogue.  The host rebuilds
-   a fold whenever W, b, gamma or beta change. */
-typedef struct { const float* w; const float* u; const float* c; } ovc_fold;
 typedef struct { ovc_mha att; ovc_ffn ffn; } ovc_enc_layer;
 typedef struct {
     ovc_mha self_att, cross_att;
     ovc_ffn ffn;
     ovc_lin alpha[OVC_MAX_LEVELS];    /* fc_alphas (meshed decoder) or NULLs               */
-    ovc_fold cross_q_fold;            /* cross_att.q folded with self_att.ln   (optional)  */
-    ovc_fold ffn_fold;                /* ffn.fc1 folded with cross_att.ln      (optional)  */
 } ovc_dec_layer;
 
 enum { OVC_ENC_PLAIN = 0, OVC_ENC_MULTILEVEL = 1, OVC_ENC_GEOMETRIC = 2 };
@@ -321,21 +312,6 @@ int ovc_debug_force_gemm_tiling(int tiling);
 int ovc_debug_linear_tiling(const float* x, int K, const float* W, const float* bias, float* y, int M, int N,
                             int tiling, int ksplit, int iters, ovc_stream stream);
 
-/* AddNorm fused into the product that consumes it (fp32 mode; the decode step's  x1 = LayerNorm(att W_o^T + b_o + x);
- * q = x1 W_q^T + b_q  of attentions.py:304-310 -> :47, and the same pair around the feed-forward's first layer):
- *   s      = parts[0] + parts[1] + bias + residual              [M, K]  (the K-split output projection's raw slices)
- *   x_out  = LayerNorm(s) * gamma + beta                        [M, K]  written for the later readers of the AddNorm
- *   y      = act(LayerNorm(s) W^T + b)                          [M, N]  through the fold (ovc_fold_weight):
- *            y = act(rstd * (s fold_w^T - mean * fold_u) + fold_c)
- * in ONE kernel: s streams through the product's K loop as its A operand while the row moments accumulate (per 32-column block,
- * blocks combined in column order -- the same bits for every tiling), mean / rstd enter in the epilogue, and each column tile
- * writes one 32-column block of x_out.  K % 32 == 0, the four-chain K-order class; `tiling` < 0: the tuned / default tiling,
- * >= 0: that tiling (tests).  act: 0 none, 1 relu. */
-int ovc_addnorm_linear(const float* parts, long part_stride, const float* bias, const float* residual,
-                       const float* gamma, const float* beta, float eps, float* x_out,
-                       const float* fold_w, const float* fold_u, const float* fold_c, float* y,
-                       int M, int N, int K, int act, int tiling, ovc_stream stream);
-
 /* Test hook: ONE selection step of the engine's fused path on caller-supplied decoder outputs x [B*width, d] -- the
  * vocabulary product fc [V, d] with its log-softmax epilogue (transposed != 0: logits^T = fc . x^T as the fp32 engine runs
  * it; 0: the row-major form) and the fused select + update kernel, which never reads the logits back -- against which a
@@ -351,12 +327,6 @@ int ovc_debug_vocab_select(const float* x, const float* fc, const float* running
  * cutting W again in every workgroup.  ovc_split_weight_bytes = size of `planes` (0 = invalid arguments); the planes hold the
  * same bits the kernel would cut, so results do not change.  ovc_debug_linear_planes = ovc_debug_linear_tiling on them. */
 size_t ovc_split_weight_bytes(int N, int K, int mode);
-/* LayerNorm fold (ovc_fold) of nn.Linear (W [N, K], bias [N] or NULL) behind nn.LayerNorm (gamma, beta [K]):
- * w_out [N, K], u_out [N], c_out [N].  One launch; sums in double.  Replaces nothing in the reference -- it is the algebra
- *   LayerNorm(x) W^T + b = rstd (x (W gamma)^T - mean u) + (W beta + b)
- * that lets the decode step (decoders.py:28-45 -> attentions.py:304-310) skip the LayerNorm kernels between its products. */
-int ovc_fold_weight(const float* W, const float* bias, const float* gamma, const float* beta, int N, int K,
-                    float* w_out, float* u_out, float* c_out, ovc_stream stream);
 int ovc_split_weight(const float* W, int N, int K, int mode, void* planes, ovc_stream stream);
 int ovc_debug_linear_planes(const float* x, int K, const float* W, const void* planes, const float* bias, float* y,
                             int M, int N, int tiling, int ksplit, int iters, ovc_stream stream);

@@ -122,20 +122,6 @@ struct GemmArgs {
     float* stats_t;      // the same pieces for a TRANSPOSED product (rows of C are the words, columns the beam rows): per (column n,
                          // 32-row block) the maximum and sum exp over the block's rows, [seg_n][stats_ld] float2.  A lane of the
                          // accumulator then holds 16 words of ONE beam row, so the reductions are in-register (one half-wave swap each)
-    // AddNorm fused into the A side (ovc_addnorm_linear, include/ovc.h; four-chain fp32 class, nseg == 1, K2 == 0, no K split,
-    // lda1 == K1, 32 | K1): A1 = the first of TWO raw partial slices an_part_stride floats apart; the operand the product sees is
-    //   s = ((A1[0] + A1[1]) + an_bias) + an_res                       (the order the LayerNorm kernel sums in)
-    // seg[0].W is the gamma-folded weight; the rows' moments accumulate while s streams through the K loop, fold_u / fold_c finish
-    // LayerNorm(s) W^T + b in the epilogue and an_x receives LayerNorm(s) * an_g + an_b.  an_res != nullptr switches it on.
-    const float* an_res;
-    const float* an_bias;
-    const float* an_g;
-    const float* an_b;
-    float* an_x;
-    long an_part_stride;
-    float an_eps;
-    const float* fold_u; // [seg_n]  sum_k W[n,k] gamma[k]
-    const float* fold_c; // [seg_n]  sum_k W[n,k] beta[k] + b[n]
     int objective;       // which tuning table to consult: 0 / 1 = measured in isolation, c > 1 = measured with c co-running copies
                          // (speed only: every tiling of the class gives the same bits)
     GemmSegment seg[OVC_MAX_SEGMENTS];

@@ -247,17 +247,6 @@ int decode_ksplit(int K) {
     return s;
 }
 
-// AddNorm fused into its consumer (ovc_addnorm_linear, include/ovc.h) applies to a decoder layer when the host supplied the
-// folds (fp32 mode), the layer has no AoA gates (they read the AddNorm's output before the consumer does), the output projections
-// run as two K slices and the widths are whole K tiles.  Without folds every AddNorm is one LayerNorm kernel (the host's A/B
-// switch: CaptionEngine.fused_add_norm / OVC_EAGER_LAYER_NORM).
-bool fused_add_norm(const ovc_model* m, const ovc_dec_layer& dl) {
-    if (m->precision != 0 || m->dec_kind != OVC_DEC_PLAIN || (m->d_model & 31)) return false;
-    if (dl.self_att.aoa_i.w || dl.cross_att.aoa_i.w || !dl.self_att.o.b || !dl.cross_att.o.b) return false;
-    if (decode_ksplit(m->heads * m->d_v) != 2) return false;
-    return dl.cross_q_fold.w && dl.cross_q_fold.u && dl.cross_q_fold.c && dl.ffn_fold.w && dl.ffn_fold.u && dl.ffn_fold.c;
-}
-
 using GemmShape = std::array<int, 7>;               // M, seg_n, nseg, K, kchains, ksplit, epilogue (0 plain, 1 stats, 2 stats_t)
 
 struct Engine {
@@ -321,24 +310,6 @@ struct Engine {
     // out = LayerNorm(x W^T + b + residual), rows flagged in zero_rows cleared.  With a partial-product buffer (the
     // M = B*k decode-step projections back to d_model) the GEMM runs as decode_ksplit(K) slices writing raw partial
     // products; the LayerNorm kernel sums them in slice order and applies bias and residual.
-    // x_out = LayerNorm(att W_o^T + b_o + residual);  y = act(x_out W^T + b)  as two launches: the output projection's two raw K
-    // slices, then the consumer product with the AddNorm on its A side (GemmArgs::an_res).
-    int addnorm_linear(const float* att, int K, const ovc_lin& o, const float* residual, const ovc_norm& ln, float* part,
-                       float* x_out, const ovc_fold& fold, float* y, int M, int N, int act) {
-        const int d = m->d_model;
-        GemmArgs a{};
-        a.A1 = att; a.lda1 = K; a.K1 = K; a.M = M; a.seg_n = d; a.nseg = 1; a.ldc = d;
-        a.ksplit = 2; a.part_stride = (long)M * d;
-        a.seg[0] = seg(o, part); a.seg[0].bias = nullptr;
-        TRY(gemm(a));
-        GemmArgs b{};
-        b.A1 = part; b.lda1 = d; b.K1 = d; b.M = M; b.seg_n = N; b.nseg = 1; b.ldc = N; b.act = act;
-        b.seg[0] = GemmSegment{fold.w, nullptr, y, nullptr, nullptr};
-        b.an_res = residual; b.an_bias = o.b; b.an_g = ln.g; b.an_b = ln.b; b.an_x = x_out; b.an_part_stride = a.part_stride;
-        b.an_eps = m->ln_eps; b.fold_u = fold.u; b.fold_c = fold.c;
-        return gemm(b);
-    }
-
     int linear_ln(const float* x, int K, const ovc_lin& l, const float* residual, const ovc_norm& ln,
                   const uint8_t* zero_rows, float* y_tmp, float* part, float* out, int M) {
         const int d = m->d_model;
@@ -514,17 +485,11 @@ int run_decode_step(Engine& e, Workspace& w, int B, int N, int k, int t, int ret
         sa.anc = w.anc[cur]; sa.anc_ld = T; sa.padflag = w.padflag; sa.pad_ld = R; sa.t = t; sa.width = width;
         sa.h = m->heads; sa.dk = m->d_k; sa.dv = m->d_v; sa.out = w.att; sa.ldo = hv;
         if (!(debug_skip() & 2)) RUN(ovc_decode_self_attention(sa, rows, s));
-        const bool fused = fused_add_norm(m, dl);
-        if (fused) {
-            // the self-attention AddNorm rides on the cross-attention's query projection: one launch instead of two
-            TRY(e.addnorm_linear(w.att, hv, dl.self_att.o, x, dl.self_att.ln, w.part, w.x1, dl.cross_q_fold, w.q, rows, hk, 0));
-        } else {
-            TRY(e.linear_ln(w.att, hv, dl.self_att.o, x, dl.self_att.ln, nullptr, w.y, w.part, w.x1, rows));
-            TRY(e.aoa(dl.self_att, x, w.x1, w.info, w.gate, rows));
-            TRY(e.linear(w.x1, d, dl.cross_att.q, nullptr, w.q, rows, hk, 0));
-        }
+        TRY(e.linear_ln(w.att, hv, dl.self_att.o, x, dl.self_att.ln, nullptr, w.y, w.part, w.x1, rows));
+        TRY(e.aoa(dl.self_att, x, w.x1, w.info, w.gate, rows));
 
         // ---- cross-attention: the image's beams share its projected encoder keys/values -----------
+        TRY(e.linear(w.x1, d, dl.cross_att.q, nullptr, w.q, rows, hk, 0));
         DecodeCrossArgs ca{};
         ca.q = w.q; ca.ldq = hk;
         ca.kx = w.kx + (size_t)l * lv * B * N * hk; ca.vx = w.vx + (size_t)l * lv * B * N * hv;
@@ -570,12 +535,6 @@ int run_decode_step(Engine& e, Workspace& w, int B, int N, int k, int t, int ret
             }
             RUN(ovc_meshed_mix(w.alpha, w.enc_att, lv, (long)nrd, sqrtf((float)lv), w.mixed, s));
             ffn_in = w.mixed;
-        } else if (fused) {
-            // the cross-attention AddNorm rides on the feed-forward's first layer; its second layer keeps the K-split + LayerNorm pair
-            TRY(e.addnorm_linear(w.att, hv, dl.cross_att.o, w.x1, dl.cross_att.ln, w.part, w.x2, dl.ffn_fold, w.ff, rows, m->d_ff, 1));
-            TRY(e.linear_ln(w.ff, m->d_ff, dl.ffn.fc2, w.x2, dl.ffn.ln, padflag_t, w.y, w.part, w.x, rows));
-            x = w.x;
-            continue;
         } else {
             TRY(e.linear_ln(w.att, hv, dl.cross_att.o, w.x1, dl.cross_att.ln, nullptr, w.y, w.part, w.x2, rows));
             TRY(e.aoa(dl.cross_att, w.x1, w.x2, w.info, w.gate, rows));
@@ -659,7 +618,7 @@ int run_decode_step(Engine& e, Workspace& w, int B, int N, int k, int t, int ret
 
 }  // namespace
 
-extern "C" int ovc_abi_version(void) { return 7; }
+extern "C" int ovc_abi_version(void) { return 6; }
 
 extern "C" const char* ovc_build_info(void) {
     return "libovc gfx950 (CDNA4) fp32: v_mfma_f32_32x32x2_f32 GEMM + attention, HIP " __DATE__;

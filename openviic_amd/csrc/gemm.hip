@@ -127,13 +127,9 @@ __device__ __forceinline__ void tile_coords(int tiles_m, int group_m, int xcd_pm
 // descriptors: one per-lane byte offset (first row of the lane's 16, its column) and a scalar row offset per accumulator
 // register; rows past M fall outside the descriptor and are dropped by the hardware, columns past seg_n get an
 // out-of-range offset.  (m0, n0) = first row / column of the wave's tiles.
-// Fused AddNorm (GemmArgs::an_res): lnrow = (mean, rstd) of the wave's rows in LDS; the accumulator holds s (W gamma)^T and
-// LayerNorm(s) W^T + b = rstd * (acc - mean * u) + c.
 template <int TM, int TN>
-__device__ __forceinline__ void store_wave_tiles(const GemmArgs& p, int seg, const f32x16 (&acc)[TM][TN], int m0, int n0, int lane,
-                                                 const float* lnrow = nullptr) {
+__device__ __forceinline__ void store_wave_tiles(const GemmArgs& p, int seg, const f32x16 (&acc)[TM][TN], int m0, int n0, int lane) {
     const float* __restrict__ bias = p.seg[seg].bias;
-    const bool folded = lnrow != nullptr;                          // uniform
     float* __restrict__ C = p.seg[seg].C + (size_t)blockIdx.y * p.part_stride;
     const int half = lane >> 5;
     const bool has_res = p.R != nullptr;                          // uniform
@@ -145,23 +141,14 @@ __device__ __forceinline__ void store_wave_tiles(const GemmArgs& p, int seg, con
     for (int j = 0; j < TN; ++j) {
         const int n = n0 + j * 32 + (lane & 31);
         const bool n_ok = n < p.seg_n;
-        const int nc = min(n, p.seg_n - 1);
-        const float bv = folded ? p.fold_c[nc] : (bias ? bias[nc] : 0.f);
-        const float uv = folded ? p.fold_u[nc] : 0.f;
+        const float bv = bias ? bias[min(n, p.seg_n - 1)] : 0.f;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             const int mbase = m0 + i * 32 + 4 * half;
             float out[16];
-            // (mean, rstd) of register r's row: read from LDS at the use, not held (the 32x32 tilings have no registers to spare)
-            const float* lnr = lnrow + 2 * (i * 32 + 4 * half);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                float v = acc[i][j][r];
-                if (folded) {
-                    const f32x2 mr = *reinterpret_cast<const f32x2*>(lnr + 2 * ((r & 3) + 8 * (r >> 2)));
-                    v = mr[1] * (v - mr[0] * uv);
-                }
-                v += bv;
+                const float v = acc[i][j][r] + bv;
                 out[r] = p.act == 1 ? fmaxf(v, 0.f) : v;
             }
             if (has_res) {
@@ -240,25 +227,9 @@ __device__ __forceinline__ void store_wave_tiles(const GemmArgs& p, int seg, con
 template <int BM, int BN, int BK, int NC>
 constexpr int min_waves_per_simd() { return BM * BN <= 32 * 64 ? 5 : (BM * BN <= 64 * 64 ? (NC == 4 && BK == 64 ? 3 : 4) : 1); }
 
-// One step of a row's running moments (fused AddNorm): block b (32 columns: mean mb, squared deviations from it q) joins the
-// b blocks before it -- Chan et al.'s pairwise update, in column order.  Contraction is off and the fused multiply-adds are
-// explicit: every instance of the template has to round the same way, or the tiling would show in the bits.
-__device__ __forceinline__ void moments_join(float& mean, float& m2, float mb, float q, int b) {
-#pragma clang fp contract(off)
-    if (b == 0) { mean = mb; m2 = q; return; }
-    const float delta = mb - mean;
-    const float w = 1.0f / (float)(b + 1);
-    mean = __builtin_fmaf(delta, w, mean);
-    m2 = m2 + __builtin_fmaf(delta * delta, 32.0f * (float)b * w, q);
-}
-
-// FA: the fused-AddNorm form (GemmArgs::an_res; four-chain instances only) -- A is summed from its sources as it is staged,
-// the rows' moments accumulate on the way, the epilogue applies them.
-template <int BM, int BN, int WM, int WN, int WK, int BK, int NC, bool FA = false>
+template <int BM, int BN, int WM, int WN, int WK, int BK, int NC>
 __global__ __launch_bounds__(256, (min_waves_per_simd<BM, BN, BK, NC>())) void gemm_f32_mfma(GemmArgs p, int tiles_m, int tiles_n_per_seg, int group_m, int xcd_pm) {
     using Cfg = TileConfig<BM, BN, WM, WN, WK, BK, NC>;
-    static_assert(!FA || (Cfg::kChains == 4 && BK == 32), "fused AddNorm: four-chain class, one 32-column block per K tile");
-    __shared__ float lnrow[FA ? 2 * BM : 1];         // FA: (mean, rstd) of the workgroup's rows
     constexpr int LDT = Cfg::LDT;
     constexpr int kVecPerRow = BK / 4;               // float4 per tile row
     constexpr int kRowsPerPass = 256 / kVecPerRow;   // tile rows covered by one pass of the 256 loader threads
@@ -306,13 +277,6 @@ __global__ __launch_bounds__(256, (min_waves_per_simd<BM, BN, BK, NC>())) void g
     const __amdgpu_buffer_rsrc_t rsrc_a2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.K2 ? a2 : p.A1), 0,
                                                                               p.K2 ? p.M * p.lda2 * 4 : 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(W), 0, p.seg_n * K * 4, 0x00020000);
-    // FA: the second partial slice and the residual share A1's offsets (same shape, row stride K)
-    const __amdgpu_buffer_rsrc_t rsrc_p1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(FA ? p.A1 + p.an_part_stride : p.A1), 0,
-                                                                              FA ? p.M * p.lda1 * 4 : 0, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsrc_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(FA ? p.an_res : p.A1), 0,
-                                                                              FA ? p.M * p.lda1 * 4 : 0, 0x00020000);
-    f32x4 stage_p1[FA ? Cfg::kLoadA : 1], stage_rs[FA ? Cfg::kLoadA : 1], stage_bias;
-    float row_mean[FA ? Cfg::kLoadA : 1], row_m2[FA ? Cfg::kLoadA : 1];
     int off_a1[Cfg::kLoadA], off_a2[Cfg::kLoadA], off_w[Cfg::kLoadB];
     {
         const int kq = tid % kVecPerRow;
@@ -333,15 +297,7 @@ __global__ __launch_bounds__(256, (min_waves_per_simd<BM, BN, BK, NC>())) void g
             a_ok = (second ? k0 - p.K1 : k0) + kq * 4 < (second ? p.K2 : p.K1);
             w_ok = k0 + kq * 4 < K;
         }
-        if constexpr (FA) {
-#pragma unroll
-            for (int i = 0; i < Cfg::kLoadA; ++i) {
-                stage_a[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_a1, off_a1[i], k0 * 4, 0));
-                stage_p1[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_p1, off_a1[i], k0 * 4, 0));
-                stage_rs[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_rs, off_a1[i], k0 * 4, 0));
-            }
-            stage_bias = *reinterpret_cast<const f32x4*>(p.an_bias + k0 + (tid % kVecPerRow) * 4);
-        } else if (!second) {
+        if (!second) {
 #pragma unroll
             for (int i = 0; i < Cfg::kLoadA; ++i)
                 stage_a[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_a1, off_a1[i], k0 * 4, 0));
@@ -361,30 +317,8 @@ __global__ __launch_bounds__(256, (min_waves_per_simd<BM, BN, BK, NC>())) void g
     float rs[Cfg::kLoadA];
 #pragma unroll
     for (int i = 0; i < Cfg::kLoadA; ++i) rs[i] = 0.f;
-    auto store_tile = [&](int buf, int kt) {
+    auto store_tile = [&](int buf) {
         const int kq = tid % kVecPerRow;
-        if constexpr (FA) {
-            // the operand: s = ((p0 + p1) + bias) + residual, the LayerNorm kernel's own order; and its moments per 32-column
-            // block: the 8 lanes that staged a block's 8 column groups all-reduce (commutative pair exchanges: the same bits in
-            // every lane), the block joins the row's running moments in column order.  (K tiles of 32: one block per tile.)
-#pragma clang fp contract(off)
-#pragma unroll
-            for (int i = 0; i < Cfg::kLoadA; ++i) {
-                const f32x4 v = ((stage_a[i] + stage_p1[i]) + stage_bias) + stage_rs[i];
-                stage_a[i] = v;
-                float sum = (v[0] + v[1]) + (v[2] + v[3]);
-                sum += ovc_dpp<0xB1>(sum);
-                sum += ovc_dpp<0x4E>(sum);
-                sum += ovc_dpp<0x141>(sum);
-                const float mb = sum * (1.0f / 32.0f);
-                const f32x4 d = v - mb;
-                float q = (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
-                q += ovc_dpp<0xB1>(q);
-                q += ovc_dpp<0x4E>(q);
-                q += ovc_dpp<0x141>(q);
-                moments_join(row_mean[i], row_m2[i], mb, q, kt);
-            }
-        }
         if (k_tail) {
 #pragma unroll
             for (int i = 0; i < Cfg::kLoadA; ++i)
@@ -420,7 +354,7 @@ __global__ __launch_bounds__(256, (min_waves_per_simd<BM, BN, BK, NC>())) void g
                 for (int r = 0; r < 16; ++r) acc[c][i][j][r] = 0.f;
 
     load_tile(0);
-    store_tile(0, 0);
+    store_tile(0);
     __syncthreads();
 
     const int frag_row = lane & 31;
@@ -463,7 +397,7 @@ __global__ __launch_bounds__(256, (min_waves_per_simd<BM, BN, BK, NC>())) void g
 
         if (kt + 1 < nkt) {
             if (Cfg::kBufs == 1) __syncthreads();
-            store_tile(Cfg::kBufs == 2 ? (buf ^ 1) : 0, kt + 1);
+            store_tile(Cfg::kBufs == 2 ? (buf ^ 1) : 0);
         }
         __syncthreads();
     }
@@ -477,41 +411,6 @@ __global__ __launch_bounds__(256, (min_waves_per_simd<BM, BN, BK, NC>())) void g
             for (int off = 1; off < kVecPerRow; off <<= 1) v += __shfl_xor(v, off, 64);
             const int row = m0 + tid / kVecPerRow + i * kRowsPerPass;
             if (tid % kVecPerRow == 0 && row < p.M) p.zero_rows_out[row] = (v == 0.f) ? 1 : 0;
-        }
-    }
-
-    // Fused AddNorm: the rows' moments are complete.  Their (mean, rstd) go to LDS for the epilogue, and the normalised rows are
-    // written out for the AddNorm's later readers: column tile j of this row block writes the 32-column blocks j, j + tiles_n, ...
-    // -- by the waves that have no epilogue to run (chains spread over waves), else by everybody before the epilogue.
-    auto write_normalised_rows = [&](int t, int nthreads) {
-        if constexpr (FA) {
-#pragma clang fp contract(off)
-            for (int blk = tile_n; blk < (K >> 5); blk += tiles_n_per_seg) {
-                for (int e = t; e < BM * 8; e += nthreads) {
-                    const int row = e >> 3, c = blk * 32 + (e & 7) * 4;
-                    if (m0 + row >= p.M) continue;
-                    const size_t at = (size_t)(m0 + row) * K + c;
-                    const f32x4 v = ((*reinterpret_cast<const f32x4*>(p.A1 + at) + *reinterpret_cast<const f32x4*>(p.A1 + p.an_part_stride + at)) +
-                                     *reinterpret_cast<const f32x4*>(p.an_bias + c)) + *reinterpret_cast<const f32x4*>(p.an_res + at);
-                    const f32x4 g = *reinterpret_cast<const f32x4*>(p.an_g + c), bt = *reinterpret_cast<const f32x4*>(p.an_b + c);
-                    const float mean = lnrow[2 * row], rstd = lnrow[2 * row + 1];
-                    *reinterpret_cast<f32x4*>(p.an_x + at) = (v - mean) * rstd * g + bt;
-                }
-            }
-        }
-    };
-    if constexpr (FA) {
-        if (tid % kVecPerRow == 0) {
-#pragma unroll
-            for (int i = 0; i < Cfg::kLoadA; ++i) {
-                const int row = tid / kVecPerRow + i * kRowsPerPass;
-                lnrow[2 * row] = row_mean[i];
-                lnrow[2 * row + 1] = 1.0f / sqrtf(row_m2[i] / (float)K + p.an_eps);
-            }
-        }
-        if constexpr (WK == 1) {
-            __syncthreads();
-            write_normalised_rows(tid, 256);
         }
     }
 
@@ -536,10 +435,7 @@ __global__ __launch_bounds__(256, (min_waves_per_simd<BM, BN, BK, NC>())) void g
                             for (int r = 0; r < 16; ++r) red[red_index(wk, c, i, j, r)] = acc[c][i][j][r];
             }
             __syncthreads();
-            if (wk > 0) {
-                write_normalised_rows(tid - 64 * WM * WN, 256 - 64 * WM * WN);
-                return;
-            }
+            if (wk > 0) return;
         }
 #pragma unroll
         for (int chain = 1; chain < Cfg::kChains; ++chain) {
@@ -555,8 +451,7 @@ __global__ __launch_bounds__(256, (min_waves_per_simd<BM, BN, BK, NC>())) void g
         }
     }
 
-    store_wave_tiles<Cfg::TM, Cfg::TN>(p, seg, acc[0], m0 + wm * Cfg::kWaveM, n0 + wn * Cfg::kWaveN, lane,
-                                       FA ? lnrow + 2 * wm * Cfg::kWaveM : nullptr);
+    store_wave_tiles<Cfg::TM, Cfg::TN>(p, seg, acc[0], m0 + wm * Cfg::kWaveM, n0 + wn * Cfg::kWaveN, lane);
 }
 
 // tile order shared by both kernels: super-rows of M tiles when the A panel exceeds an L2, else the 2-D XCD split with
@@ -606,25 +501,6 @@ int launch_config(const GemmArgs& a, hipStream_t stream, const GemmLaunchOpts& o
     // opts.copies (tuner only): gridDim.z identical copies of the product in one launch (the kernel ignores
     // blockIdx.z), a proxy for "this many batches in flight" that needs no extra streams.
     const dim3 grid3(grid, slices, opts.copies > 1 ? opts.copies : 1);
-    if (a.an_res) {                  // fused AddNorm: the four-chain instances carry a second form of the kernel
-        if constexpr (Cfg::kChains == 4 && BK == 32) {
-            if ((a.K1 % BK) || a.K2 || slices > 1 || a.nseg != 1) return OVC_EINVAL;
-            static std::once_flag attr_once_fa;
-            std::call_once(attr_once_fa, [&] {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f32_mfma<BM, BN, WM, WN, WK, BK, NC, true>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-            });
-            if (opts.start && opts.stop)
-                hipExtLaunchKernelGGL((gemm_f32_mfma<BM, BN, WM, WN, WK, BK, NC, true>), grid3, dim3(256), (uint32_t)lds_bytes, stream,
-                                      opts.start, opts.stop, 0, a, tiles_m, tiles_n, group_m, xcd_pm);
-            else
-                hipLaunchKernelGGL((gemm_f32_mfma<BM, BN, WM, WN, WK, BK, NC, true>), grid3, dim3(256), lds_bytes, stream, a, tiles_m, tiles_n, group_m, xcd_pm);
-            OVC_RETURN_IF_LAUNCH_FAILED();
-            return OVC_OK;
-        } else {
-            return OVC_EINVAL;
-        }
-    }
     if (opts.start && opts.stop)     // kernel-scoped events: the dispatch packet's own begin / end timestamps
         hipExtLaunchKernelGGL((gemm_f32_mfma<BM, BN, WM, WN, WK, BK, NC>), grid3, dim3(256), (uint32_t)lds_bytes, stream,
                               opts.start, opts.stop, 0, a, tiles_m, tiles_n, group_m, xcd_pm);
@@ -835,12 +711,6 @@ int ovc_gemm_launch(const GemmArgs& a, hipStream_t stream, const GemmLaunchOpts&
     if (a.zero_rows_out && (a.K2 || a.ksplit > 1 || a.kchains > kSplitClass)) return OVC_EINVAL;
     if (a.stats && (a.nseg != 1 || a.ksplit > 1 || !ovc_aligned16(a.stats) || a.stats_ld < (a.seg_n + 31) / 32)) return OVC_EINVAL;
     if (a.stats_t && (a.stats || a.seg[0].bias || a.nseg != 1 || a.ksplit > 1 || !ovc_aligned16(a.stats_t) || a.stats_ld < (a.M + 31) / 32)) return OVC_EINVAL;
-    if (a.an_res || a.fold_u || a.fold_c) {              // fused AddNorm: see GemmArgs::an_res
-        if (!a.an_res || !a.an_bias || !a.an_g || !a.an_b || !a.an_x || !a.fold_u || !a.fold_c || !(a.an_eps > 0.f)) return OVC_EINVAL;
-        if (a.kchains != 4 || a.nseg != 1 || a.K2 || a.ksplit > 1 || a.R || a.lda1 != a.K1 || (a.K1 & 31) || a.zero_rows_out || a.stats || a.stats_t) return OVC_EINVAL;
-        if (a.an_part_stride < (long)a.M * a.K1 || (a.an_part_stride & 3)) return OVC_EINVAL;
-        if (!ovc_aligned16(a.an_res) || !ovc_aligned16(a.an_bias) || !ovc_aligned16(a.an_g) || !ovc_aligned16(a.an_b) || !ovc_aligned16(a.an_x)) return OVC_EINVAL;
-    }
     if (a.K2 > 0 && (a.K1 % 32)) return OVC_EINVAL;      // the A1|A2 seam must fall on a K-tile boundary
     if (a.ksplit > 1) {                                  // raw partial products: see GemmArgs::ksplit
         if (a.ksplit > kMaxKSplit || a.nseg != 1 || a.K2 || a.R || a.act || a.seg[0].bias) return OVC_EINVAL;
@@ -855,15 +725,7 @@ int ovc_gemm_launch(const GemmArgs& a, hipStream_t stream, const GemmLaunchOpts&
         (long)(a.seg_n + 256) * K * 4 > kMaxBytes || (long)(a.M + 256) * a.ldc * 4 > kMaxBytes ||
         (a.R && (long)(a.M + 256) * a.ldr * 4 > kMaxBytes)) return OVC_EINVAL;
 
-    int pick = ovc_gemm_pick_tiling(a, opts);
-    if (a.an_res && pick >= 0 && pick < kNumTilings && kTilings[pick].bk == 64 && opts.forced_tiling < 0) {
-        // fused AddNorm exists for the K-tile-32 instances (three sources per A element: the K-tile-64 ones would spill):
-        // take the same tile with the shallower K tile
-        for (int t = 0; t < kNumTilings; ++t) {
-            const TilingInfo &c = kTilings[t], &w = kTilings[pick];
-            if (!c.planes && c.bm == w.bm && c.bn == w.bn && c.wm == w.wm && c.wn == w.wn && c.wk == w.wk && c.nc == w.nc && c.bk == 32) { pick = t; break; }
-        }
-    }
+    const int pick = ovc_gemm_pick_tiling(a, opts);
     switch (pick) {
 #define OVC_TILING_CASE(id, bm, bn, wm, wn, wk, bk, nc) case id: return launch_config<bm, bn, wm, wn, wk, bk, nc>(a, stream, opts);
 #define OVC_SPLIT_CASE(id, bm, bn, wm, wn, bk, planes) case id: return launch_split_config<bm, bn, wm, wn, bk, planes>(a, stream, opts);
@@ -1058,22 +920,6 @@ extern "C" int ovc_debug_linear_tiling(const float* x, int K, const float* W, co
         if (rc != OVC_OK) return rc;
     }
     return OVC_OK;
-}
-
-extern "C" int ovc_addnorm_linear(const float* parts, long part_stride, const float* bias, const float* residual,
-                                  const float* gamma, const float* beta, float eps, float* x_out,
-                                  const float* fold_w, const float* fold_u, const float* fold_c, float* y,
-                                  int M, int N, int K, int act, int tiling, ovc_stream stream) {
-    if (!parts || !fold_w || !y || tiling >= kNumTilings) return OVC_EINVAL;
-    GemmArgs a{};
-    a.A1 = parts; a.lda1 = K; a.K1 = K; a.M = M; a.seg_n = N; a.nseg = 1; a.ldc = N; a.kchains = 4; a.act = act;
-    a.seg[0] = GemmSegment{fold_w, nullptr, y, nullptr, nullptr};
-    a.an_res = residual; a.an_bias = bias; a.an_g = gamma; a.an_b = beta; a.an_x = x_out; a.an_part_stride = part_stride; a.an_eps = eps;
-    a.fold_u = fold_u; a.fold_c = fold_c;
-    a.objective = 1;
-    GemmLaunchOpts opts{};
-    opts.forced_tiling = tiling;
-    return ovc_gemm_launch(a, ovc_hip_stream(stream), opts);
 }
 
 extern "C" int ovc_linear(const float* x, int ldx, const float* x2, int ldx2, int K1, int K2,

@@ -108,33 +108,6 @@ int launch_layer_norm(const float* x, long part_stride, const float* bias, const
     return OVC_OK;
 }
 
-// LayerNorm fold of a projection (ovc_fold, include/ovc.h): one wave per output row n.  u sums the ROUNDED folded weights
-// (the values the product multiplies by) and both sums run in double, so the fold adds one fp32 rounding per element, not K.
-__global__ __launch_bounds__(256) void fold_weight_kernel(const float* __restrict__ W, const float* __restrict__ bias,
-                                                          const float* __restrict__ gamma, const float* __restrict__ beta, int N, int K,
-                                                          float* __restrict__ w_out, float* __restrict__ u_out, float* __restrict__ c_out) {
-    const int lane = threadIdx.x & 63;
-    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (n >= N) return;
-    double u = 0.0, c = 0.0;
-    for (int k = lane; k < K; k += 64) {
-        const float wv = W[(size_t)n * K + k];
-        const float folded = wv * gamma[k];
-        w_out[(size_t)n * K + k] = folded;
-        u += (double)folded;
-        c += (double)wv * (double)beta[k];
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        u += __shfl_xor(u, off, 64);
-        c += __shfl_xor(c, off, 64);
-    }
-    if (lane == 0) {
-        u_out[n] = (float)u;
-        c_out[n] = (float)(c + (bias ? (double)bias[n] : 0.0));
-    }
-}
-
 // mask[r] = (sum_f x[r,f] == 0): one wave per row, 16-byte coalesced loads.
 __global__ __launch_bounds__(256) void zero_row_mask_kernel(const float* __restrict__ x, int rows, int d, uint8_t* __restrict__ mask) {
     const int lane = threadIdx.x & 63;
@@ -318,15 +291,6 @@ int ovc_layer_norm_parts(const float* parts, int nparts, long part_stride, const
     if (nparts == 2) return launch_layer_norm<2, true, true>(parts, part_stride, bias, residual, gamma, beta, nullptr, 0, zero_rows, eps, y, rows, d, stream);
     if (nparts == 4) return launch_layer_norm<4, true, true>(parts, part_stride, bias, residual, gamma, beta, nullptr, 0, zero_rows, eps, y, rows, d, stream);
     return OVC_EINVAL;
-}
-
-extern "C" int ovc_fold_weight(const float* W, const float* bias, const float* gamma, const float* beta, int N, int K,
-                               float* w_out, float* u_out, float* c_out, ovc_stream stream) {
-    if (const int rc = ovc_device_guard()) return rc;
-    if (!W || !gamma || !beta || !w_out || !u_out || !c_out || N <= 0 || K <= 0 || (K & 3) || !ovc_aligned16(w_out)) return OVC_EINVAL;
-    hipLaunchKernelGGL(fold_weight_kernel, dim3((N + 3) / 4), dim3(256), 0, ovc_hip_stream(stream), W, bias, gamma, beta, N, K, w_out, u_out, c_out);
-    OVC_RETURN_IF_LAUNCH_FAILED();
-    return OVC_OK;
 }
 
 extern "C" int ovc_zero_row_mask(const float* x, int rows, int d, uint8_t* mask, ovc_stream stream) {

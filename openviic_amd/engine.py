@@ -73,39 +73,6 @@ class _WeightPlanes:
                 torch.cuda.current_stream().synchronize()
 
 
-class _Folds:
-    """LayerNorm folds (``ovc_fold``, include/ovc.h) of the projections that read a LayerNorm's output in the decode
-    step: ``w = W * gamma``, ``u = rowsum(w)``, ``c = W beta + b``, built by ``ovc_fold_weight`` and rebuilt when one of the
-    four source tensors' version counters moved."""
-
-    def __init__(self, lib):
-        self.lib, self.entries, self.lock = lib, [], threading.Lock()
-
-    def add(self, dst, linear, ln):
-        n, k = linear.weight.shape
-        dev = linear.weight.device
-        bufs = (torch.empty(n, k, device=dev), torch.empty(n, device=dev), torch.empty(n, device=dev))
-        self.entries.append([linear, ln, bufs, None])
-        dst.w, dst.u, dst.c = (b.data_ptr() for b in bufs)
-
-    @staticmethod
-    def _versions(linear, ln):
-        return (linear.weight._version, linear.bias._version if linear.bias is not None else -1, ln.weight._version, ln.bias._version)
-
-    def refresh(self, force=False):
-        with self.lock:
-            stale = [e for e in self.entries if force or self._versions(e[0], e[1]) != e[3]]
-            for entry in stale:
-                linear, ln, (w, u, c), _ = entry
-                n, k = linear.weight.shape
-                check(self.lib.ovc_fold_weight(_p(linear.weight.detach()), _p(linear.bias.detach()) if linear.bias is not None else None,
-                                               _p(ln.weight.detach()), _p(ln.bias.detach()), n, k, w.data_ptr(), u.data_ptr(),
-                                               c.data_ptr(), native.stream_handle()), "ovc_fold_weight")
-                entry[3] = self._versions(linear, ln)
-            if stale:
-                torch.cuda.current_stream().synchronize()      # other streams may decode with these buffers
-
-
 def _norm(dst, ln):
     dst.g, dst.b = _p(ln.weight.detach()), _p(ln.bias.detach())
 
@@ -151,11 +118,8 @@ class CaptionEngine:
     # workgroup of every launch -- same bits, W then bypasses conversion and LDS (OVC_PRECUT_WEIGHTS=0: A/B switch)
     precut_weights = os.environ.get("OVC_PRECUT_WEIGHTS", "1") != "0"
     precision = os.environ.get("OVC_PRECISION", "f32")
-    # fp32 mode, plain decoder layers: fold the two attention AddNorms of a decode layer into the products around them
-    # (engine.hip "fused AddNorm": 114 launches per caption batch fewer).  OVC_EAGER_LAYER_NORM=1: one kernel per AddNorm.
-    fused_add_norm = os.environ.get("OVC_EAGER_LAYER_NORM") is None
 
-    def __init__(self, model, tune_concurrency=None, precision=None, fused_add_norm=None):
+    def __init__(self, model, tune_concurrency=None, precision=None):
         self.lib = native.load()
         self.model = model
         if precision is not None:
@@ -168,10 +132,6 @@ class CaptionEngine:
         self._fc_g = None
         # split-precision modes: the GEMM weights pre-cut into 16-bit planes (read straight from memory by the kernels)
         self._planes = _WeightPlanes(self.lib) if self.precision != "f32" and self.precut_weights else None
-        # fp32 mode: gamma-folded copies of the decoder projections behind a LayerNorm (fused AddNorm, engine.hip)
-        if fused_add_norm is not None:
-            self.fused_add_norm = bool(fused_add_norm)
-        self._folds = _Folds(self.lib) if self.precision == "f32" and self.fused_add_norm else None
         self.desc = self._describe(model)
         self._workspaces = {}    # one scratch buffer per HIP stream: concurrent batches never share state
         self._tuned = set()
@@ -225,9 +185,6 @@ class CaptionEngine:
             if d.dec_kind == native.DEC_MESHED:
                 for j, fc in enumerate(layer.fc_alphas):
                     _lin(d.dec[i].alpha[j], fc, pl, mode)
-            elif self._folds is not None and not layer.self_attn.use_aoa and not layer.enc_attn.use_aoa:
-                self._folds.add(d.dec[i].cross_q_fold, layer.enc_attn.attention.fc_q, layer.self_attn.layer_norm)
-                self._folds.add(d.dec[i].ffn_fold, layer.pwff.fc1, layer.enc_attn.layer_norm)
         d.word_emb = _p(dec.word_emb.components.weight.detach())
         d.pos_emb = _p(dec.pos_emb.weight.detach())
         d.fc = _p(dec.fc.weight.detach())
@@ -252,16 +209,12 @@ class CaptionEngine:
             torch.cat([fc.bias.detach() for fc in enc.fc_gs], dim=0, out=self._fc_g[1])
         if self._planes is not None:
             self._planes.refresh()
-        if self._folds is not None:
-            self._folds.refresh()
 
     def recut_weights(self):
         """Split-precision modes: rebuild every weight's pre-cut planes (only needed after modifying weights in a way that
         does not move their version counter, e.g. through ``.data``)."""
         if self._planes is not None:
             self._planes.refresh(force=True)
-        if self._folds is not None:
-            self._folds.refresh(force=True)
 
     # -- GEMM tiling selection ------------------------------------------------------------------
     def gemm_shapes(self, B, N, k):

@@ -12,7 +12,7 @@ OVC_MAX_LAYERS = 8
 OVC_MAX_LEVELS = 4
 OVC_MAX_BEAM = 8
 OVC_PROFILE_CLASSES = 4
-ABI_VERSION = 7
+ABI_VERSION = 6
 
 _ERRORS = {-1: "OVC_EINVAL (bad argument / unsupported shape)", -2: "OVC_EWORKSPACE (workspace too small)",
            -3: "OVC_ELAUNCH (HIP launch failed)",
@@ -44,13 +44,8 @@ class EncLayer(ctypes.Structure):
     _fields_ = [("att", Mha), ("ffn", Ffn)]
 
 
-class Fold(ctypes.Structure):
-    _fields_ = [("w", c_void_p), ("u", c_void_p), ("c", c_void_p)]
-
-
 class DecLayer(ctypes.Structure):
-    _fields_ = [("self_att", Mha), ("cross_att", Mha), ("ffn", Ffn), ("alpha", Lin * OVC_MAX_LEVELS),
-                ("cross_q_fold", Fold), ("ffn_fold", Fold)]
+    _fields_ = [("self_att", Mha), ("cross_att", Mha), ("ffn", Ffn), ("alpha", Lin * OVC_MAX_LEVELS)]
 
 
 class Model(ctypes.Structure):
@@ -112,9 +107,6 @@ SIGNATURES = {
                                        c_size_t, c_void_p, c_void_p, c_void_p]),
     "ovc_split_weight_bytes": (c_size_t, [c_int, c_int, c_int]),
     "ovc_split_weight": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
-    "ovc_addnorm_linear": (c_int, [c_void_p, c_long, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p,
-                                   c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
-    "ovc_fold_weight": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "ovc_debug_linear_planes": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                         c_void_p]),
     "ovc_debug_repeat_linear": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),

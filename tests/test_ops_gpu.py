@@ -452,73 +452,6 @@ def test_every_tiling_of_a_k_order_class_gives_the_same_bits(M, N, K):
         assert err[104] < 4 * err[1] and err[103] < 8 * err[1], err     # 22 / 24 operand bits: the fp32 path's own error level
 
 
-@pytest.mark.parametrize("M,d,N,shift,act", [(80, 512, 512, 0.0, 0), (1280, 512, 2048, 3.0, 1), (37, 96, 64, -50.0, 0), (130, 1088, 160, 0.5, 1),
-                                            (1, 32, 8, 0.0, 0)])
-def test_addnorm_linear_matches_layer_norm_then_linear(M, d, N, shift, act):
-    """ovc_addnorm_linear (the decode step's AddNorm fused into the product that consumes it, include/ovc.h): the two raw K slices
-    of an output projection + bias + residual stream through the consumer's K loop, the row moments accumulate on the way (per
-    32-column block, blocks joined in column order), LayerNorm enters through the gamma-folded weight and the epilogue, and the
-    normalised rows are written for later readers.  Against fp64 LayerNorm + Linear (row means far from zero -- ``shift`` --
-    included: the moments are block-wise deviations, not E[x^2] - mean^2), for every K-tile-32 tiling of the four-chain class, bit for
-    bit across those tilings; the pre-LayerNorm sum must carry the LayerNorm kernel's own bits."""
-    from openviic_amd import native
-    from openviic_amd import ops
-    lib = native.load()
-    lib.ovc_profile_kernel_name.restype = __import__("ctypes").c_char_p
-    g = torch.Generator().manual_seed(M + d + N)
-    parts = torch.randn(2, M, d, generator=g)
-    bias, res = torch.randn(d, generator=g), torch.randn(M, d, generator=g) + shift
-    gamma, beta = 1 + 0.3 * torch.randn(d, generator=g), 0.2 * torch.randn(d, generator=g)
-    w, b = torch.randn(N, d, generator=g) / math.sqrt(d), torch.randn(N, generator=g)
-    eps = 1e-5
-    s64 = parts[0].double() + parts[1].double() + bias.double() + res.double()
-    x64 = torch.nn.functional.layer_norm(s64, (d,), gamma.double(), beta.double(), eps)
-    y64 = x64 @ w.double().T + b.double()
-    if act:
-        y64 = torch.relu(y64)
-    pd, bd, rd, gd, bed, wd, b2d = (t.to(DEV) for t in (parts, bias, res, gamma, beta, w, b))
-    fw, fu, fc = torch.empty(N, d, device=DEV), torch.empty(N, device=DEV), torch.empty(N, device=DEV)
-    assert lib.ovc_fold_weight(wd.data_ptr(), b2d.data_ptr(), gd.data_ptr(), bed.data_ptr(), N, d, fw.data_ptr(), fu.data_ptr(),
-                               fc.data_ptr(), native.stream_handle()) == 0
-    np.testing.assert_array_equal(fw.cpu().numpy(), (w * gamma).numpy())
-    np.testing.assert_allclose(fu.cpu().double().numpy(), (w * gamma).double().sum(1).numpy(), rtol=1e-6, atol=1e-6)
-    np.testing.assert_allclose(fc.cpu().double().numpy(), (w.double() @ beta.double() + b.double()).numpy(), rtol=1e-6, atol=1e-6)
-
-    def run(tiling):
-        x, y = torch.full((M, d), float("nan"), device=DEV), torch.full((M, N), float("nan"), device=DEV)
-        rc = lib.ovc_addnorm_linear(pd.data_ptr(), M * d, bd.data_ptr(), rd.data_ptr(), gd.data_ptr(), bed.data_ptr(), eps, x.data_ptr(),
-                                    fw.data_ptr(), fu.data_ptr(), fc.data_ptr(), y.data_ptr(), M, N, d, act, tiling, native.stream_handle())
-        return rc, x, y
-
-    first = None
-    used = 0
-    for t, name, chains in _tilings(lib):
-        k_tile = int(name.rstrip(">").split(", ")[5]) if name.startswith("gemm_f32") else 0
-        rc, x, y = run(t)
-        if chains != 4 or k_tile != 32:
-            assert rc == -1, name + " must refuse the fused form"
-            continue
-        assert rc == 0, name
-        used += 1
-        _close(x, x64, tol=2e-5, what=name + " normalised rows")
-        _close(y, y64, tol=4e-5, what=name + " product")
-        if first is None:
-            first = (name, x, y)
-        else:
-            assert torch.equal(x, first[1]) and torch.equal(y, first[2]), "%s differs from %s" % (name, first[0])
-    assert used == 5
-    rc, x, y = run(-1)                                     # the tuned / default choice
-    assert rc == 0 and torch.equal(x, first[1]) and torch.equal(y, first[2])
-    # the LayerNorm kernel on the same sources: the same rows up to the moments' summation order
-    eager = ops.layer_norm((pd[0] + pd[1]) + bd, gd, bed, residual=rd, eps=eps)
-    _close(first[1], eager, tol=2e-6, what="fused rows vs the LayerNorm kernel")
-    # argument checks
-    assert lib.ovc_addnorm_linear(pd.data_ptr(), M * d - 4, bd.data_ptr(), rd.data_ptr(), gd.data_ptr(), bed.data_ptr(), eps, first[1].data_ptr(),
-                                  fw.data_ptr(), fu.data_ptr(), fc.data_ptr(), first[2].data_ptr(), M, N, d, act, -1, native.stream_handle()) == -1
-    assert lib.ovc_addnorm_linear(pd.data_ptr(), M * d, None, rd.data_ptr(), gd.data_ptr(), bed.data_ptr(), eps, first[1].data_ptr(),
-                                  fw.data_ptr(), fu.data_ptr(), fc.data_ptr(), first[2].data_ptr(), M, N, d, act, -1, native.stream_handle()) == -1
-
-
 @pytest.mark.parametrize("M,N,K,ksplit", [(130, 200, 96, 1), (65, 33, 48, 1), (1280, 512, 512, 2), (31, 10201, 64, 1), (640, 40, 2048, 4),
                                           (5, 64, 32, 1), (257, 1536, 128, 1)])
 def test_pre_cut_weight_planes_give_the_bits_of_cutting_in_the_kernel(M, N, K, ksplit):
