@@ -203,10 +203,12 @@ typedef struct {
  * reference itself has no such limits, these are the template instances built so far:
  *   regions N <= 128;  beam k <= OVC_MAX_BEAM (8);  max_len <= 64;  any vocabulary (above 16384 words the
  *   selection streams each row k + 2 times instead of holding it in registers);
- *   d_model <= 2048 (multiple of 4);  d_k == d_v in {4, 8, 16, 32, 64}, heads <= 32, heads*d_k a multiple
- *   of 64 and <= 1024;  layers <= OVC_MAX_LAYERS (8);  meshed levels <= OVC_MAX_LEVELS (4) and equal to the
+ *   d_model <= 2048 (multiple of 4; of 32 for models with AoA gates or the meshed decoder, whose products over a
+ *   concatenated input read the two halves from their own buffers);  d_k == d_v in {4, 8, 16, 32, 64}, heads <= 32,
+ *   heads*d_k a multiple of 64 and <= 1024;  layers <= OVC_MAX_LAYERS (8);  meshed levels <= OVC_MAX_LEVELS (4) and equal to the
  *   number of encoder layers (the multilevel encoder emits one level per layer).
- * tests/test_engine_gpu.py::test_unusual_dimensions_against_oracle runs each limit against the CPU oracle.
+ * tests/test_engine_gpu.py::test_unusual_dimensions_against_oracle runs each limit against the CPU oracle,
+ * tests/test_fuzz_gpu.py a seeded random sweep of the space in between.
  *
  * Bytes of scratch the engine needs for batch B, N regions, beam k (return_probs adds the
  * [B,k,T,V] buffer).  0 on invalid arguments. */

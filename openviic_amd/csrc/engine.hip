@@ -134,6 +134,12 @@ bool model_ok(const ovc_model* m) {
     // consume exactly that many
     if (m->enc_kind == OVC_ENC_MULTILEVEL && m->n_levels != m->n_enc) return false;
     if (m->enc_kind != OVC_ENC_MULTILEVEL && m->n_levels != 1) return false;
+    // products over a concatenated input [a ; b] (AoA gates, the meshed decoder's level gates) read the two blocks from their own
+    // buffers: the seam has to fall on a K-tile boundary
+    bool two_block = m->dec_kind == OVC_DEC_MESHED;
+    for (int l = 0; l < m->n_enc; ++l) two_block = two_block || m->enc[l].att.aoa_i.w != nullptr;
+    for (int l = 0; l < m->n_dec; ++l) two_block = two_block || m->dec[l].self_att.aoa_i.w != nullptr || m->dec[l].cross_att.aoa_i.w != nullptr;
+    if (two_block && (m->d_model % 32)) return false;
     return true;
 }
 

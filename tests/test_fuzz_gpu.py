@@ -1,0 +1,109 @@
+"""Seeded random sweep of the fused engine against the CPU oracle (test infrastructure: ``oracle/``).
+
+The fixed parity cases sit at the BASELINE sizes and at hand-picked limits (``test_engine_gpu.py``); this sweep walks the space
+in between: every architecture, head counts / head sizes / widths / layer counts / memory slots / vocabulary sizes / beam widths /
+ragged region counts drawn at random (sizes the oracle finishes in well under a second), each decoded by the engine and by the
+oracle's restatement of the reference op sequence.  Bar as everywhere: padding mask bit-exact, encoder output within 2e-4 / 2e-5
+(the object-relation encoder, whose geometry bias is a log next to a ReLU's zero: relative L2 error of the output),
+token ids identical for every image whose decision margins in the oracle run exceed fp32 noise, log-probabilities within 1e-3.
+
+``OVC_FUZZ_CASES=n`` runs n cases (default 40, ~20 s); ``OVC_FUZZ_SEED`` moves the stream.
+"""
+import os
+import random
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import VARIANTS, batch, decided_images, device_model
+from openviic_amd import native
+from oracle.captioner import OracleCaptioner
+
+pytestmark = pytest.mark.gpu
+MARGIN = 2e-4
+
+# (heads, d_k) with heads * d_k a multiple of the 64-wide tile (include/ovc.h, model_ok) and d_k a power of two in 4..64
+HEAD_SHAPES = [(1, 64), (2, 32), (2, 64), (3, 64), (4, 16), (4, 32), (4, 64), (6, 32), (8, 8), (8, 16), (8, 32), (16, 4), (16, 8), (12, 16)]
+
+
+def _draw(rng):
+    variant = rng.choice(VARIANTS)
+    heads, d_kv = rng.choice(HEAD_SHAPES)
+    dims = dict(d_feature=4 * rng.randint(2, 40), d_model=32 * rng.randint(1, 8) if rng.random() < 0.7 else 4 * rng.randint(5, 60),
+                heads=heads, d_kv=d_kv, d_ff=4 * rng.randint(4, 96), layers=rng.randint(1, 4))
+    if variant in ("attention_on_attention", "meshed_memory_transformer") and rng.random() < 0.85:
+        dims["d_model"] = 32 * rng.randint(1, 8)                         # two-block products: d_model a multiple of 32 (else refused)
+    if variant == "meshed_memory_transformer":
+        dims["memory"] = rng.choice([1, 3, 8, 17, 40])
+    B, N = rng.randint(1, 7), rng.choice([1, 2, 3, 5, 8, 13, 16, 17, 31, 32, 33, 50, 64, 65])
+    V = rng.choice([5, 9, 33, 64, 100, 257, 1000, 4099])
+    T = rng.randint(2, 9)
+    k = rng.randint(1, min(5, V - 1))
+    # encoders.py:93-101: the trigonometric embedding has d_model / heads features, 8 per frequency (sin, cos of 4 box relations)
+    trig = variant == "object_relation_transformer" and rng.random() < 0.5 and (dims["d_model"] // heads) % 8 == 0 and dims["d_model"] % heads == 0
+    return variant, dims, (B, N, V, T, k), trig
+
+
+def test_random_architectures_and_shapes_against_the_oracle():
+    from openviic_amd.builders import build_model
+    from openviic_amd.config import model_config
+    from openviic_amd.utils.synthetic import SyntheticVocab, synthetic_boxes, synthetic_features, synthetic_state_dict
+    cases = int(os.environ.get("OVC_FUZZ_CASES", "40"))
+    rng = random.Random(int(os.environ.get("OVC_FUZZ_SEED", "20261004")))
+    checked_images = decided_total = refused = 0
+    for case in range(cases):
+        variant, dims, (B, N, V, T, k), trig = _draw(rng)
+        what = "case {}: {} {} B={} N={} V={} T={} k={} trig={}".format(case, variant, dims, B, N, V, T, k, trig)
+        vocab = SyntheticVocab(V, T)
+        cfg = model_config(variant, device="cpu", trignometric_embedding=trig, **dims)
+        sd = synthetic_state_dict(build_model(cfg, vocab).state_dict(), seed=1000 + case, mode="generic",
+                                  memory_dims=(dims["d_kv"], dims.get("memory", 40)))
+        feats = synthetic_features(B, N, dims["d_feature"], seed=case, ragged=True)
+        boxes = synthetic_boxes(B, N, seed=case) if variant == "object_relation_transformer" else None
+        orc = OracleCaptioner(cfg, sd, V, T)
+        rec = {}
+        want_ids, want_logp = orc.beam_search(feats, k, out_size=k, boxes=boxes, record=rec)
+        want_enc, want_mask = orc.encode(feats, boxes)
+        model = device_model(cfg, vocab, sd)
+        if variant in ("attention_on_attention", "meshed_memory_transformer") and dims["d_model"] % 32:
+            # documented limit (include/ovc.h): two-block products need the seam on a K-tile boundary -- refused up front
+            with pytest.raises(native.OvcError, match="unsupported"):
+                model.beam_search(batch(feats, boxes), batch_size=B, beam_size=k, out_size=k)
+            refused += 1
+            continue
+        try:
+            with torch.no_grad():
+                ids, logp = model.beam_search(batch(feats, boxes), batch_size=B, beam_size=k, out_size=k)
+                enc, mask = model.encoder_forward(batch(feats, boxes))
+        except Exception as error:                                      # name the case: the engine's error codes carry no shapes
+            raise AssertionError("{}: {}".format(what, error)) from error
+        assert torch.equal(mask.cpu(), want_mask), what
+        live = ~want_mask.reshape(B, -1).all(dim=1).numpy()            # an image without any region decodes to NaN in the reference
+        got_enc, ref_enc = enc.cpu().numpy()[live], want_enc.numpy()[live]
+        if variant == "object_relation_transformer":
+            # The geometry bias is log(clamp(relu(fc_g(box relations)), 1e-6)) (attentions.py:97-114): next to the ReLU's zero a
+            # rounding-level change of fc_g's output moves the bias by O(1), and the trigonometric embedding takes sin / cos of
+            # angles up to ~700 rad (one ulp of the angle: 6e-5).  Any two fp32 implementations differ in a few elements there,
+            # so this encoder is held to a norm: relative L2 error of the whole output, element-wise only at 50x the usual bound.
+            err = np.linalg.norm(got_enc - ref_enc) / max(np.linalg.norm(ref_enc), 1e-12)
+            assert err < (3e-4 if trig else 5e-5), "{}: relative L2 error {:.2e}".format(what, err)
+            np.testing.assert_allclose(got_enc, ref_enc, rtol=1e-2, atol=1e-3, err_msg=what)
+        else:
+            np.testing.assert_allclose(got_enc, ref_enc, rtol=2e-4, atol=2e-5, err_msg=what)
+        assert int(ids.min()) >= 0 and int(ids.max()) < V, what
+        gaps, inner = torch.stack(rec["gap"]).numpy(), torch.stack(rec["inner_gap"]).numpy()
+        decided = decided_images(gaps, inner, MARGIN) & live
+        if k > 1:
+            decided &= inner[-1].min(axis=1) > MARGIN                   # out_size = k: the whole final order counts
+        checked_images += B
+        decided_total += int(decided.sum())
+        np.testing.assert_array_equal(ids.cpu().numpy()[decided], want_ids.numpy()[decided], err_msg=what)
+        got, want = logp.cpu().numpy()[decided], want_logp.numpy()[decided]
+        finite = np.isfinite(want)
+        assert np.array_equal(np.isfinite(got), finite), what
+        np.testing.assert_allclose(got[finite], want[finite], rtol=0, atol=1e-3, err_msg=what)
+        model._engine.release()
+    print("[fuzz] {} cases ({} refused up front), {} images, {} decided ({:.0f} %)".format(
+        cases, refused, checked_images, decided_total, 100.0 * decided_total / max(1, checked_images)))
+    assert decided_total >= 0.5 * checked_images
