@@ -16,7 +16,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import VARIANTS, batch, decided_images, device_model
+from helpers import VARIANTS, batch, decided_images, device_model, teacher_tokens
 from openviic_amd import native
 from oracle.captioner import OracleCaptioner
 
@@ -103,6 +103,23 @@ def test_random_architectures_and_shapes_against_the_oracle():
         finite = np.isfinite(want)
         assert np.array_equal(np.isfinite(got), finite), what
         np.testing.assert_allclose(got[finite], want[finite], rtol=0, atol=1e-3, err_msg=what)
+        # every third case also takes the other entry points: the teacher-forced forward (operator path) against the oracle's,
+        # return_probs (every word's masked log-probability at every step) and out_size = 1 against the calls above
+        if case % 3 == 0:
+            tokens = teacher_tokens(B, T, V, seed=case, with_pad=T >= 4) if V > 4 else torch.ones(B, T, dtype=torch.long)
+            want_fwd = orc.forward(feats, tokens, boxes)
+            with torch.no_grad():
+                fwd = model(batch(feats, boxes, tokens))
+                ids_p, logp_p, everything = model.beam_search(batch(feats, boxes), batch_size=B, beam_size=k, out_size=k, return_probs=True)
+                ids_1, logp_1 = model.beam_search(batch(feats, boxes), batch_size=B, beam_size=k, out_size=1)
+            np.testing.assert_allclose(fwd.cpu().numpy()[live], want_fwd.numpy()[live], rtol=0, atol=1e-3, err_msg=what + " (forward)")
+            assert torch.equal(ids_p, ids) and torch.equal(logp_p, logp), what + " (return_probs changes the captions)"
+            assert tuple(everything.shape) == (B, k, T, V), what
+            ids_k, logp_k = ids.reshape(B, k, T), logp.reshape(B, k, T)            # out_size = 1 drops the beam axis
+            want_all = orc.beam_search(feats, k, out_size=k, return_probs=True, boxes=boxes)[2]
+            np.testing.assert_allclose(everything.cpu().numpy()[decided], want_all.numpy()[decided], rtol=0, atol=1e-3,
+                                       err_msg=what + " (return_probs)")
+            assert torch.equal(ids_1, ids_k[:, 0]) and torch.equal(logp_1, logp_k[:, 0]), what + " (out_size = 1)"
         model._engine.release()
     print("[fuzz] {} cases ({} refused up front), {} images, {} decided ({:.0f} %)".format(
         cases, refused, checked_images, decided_total, 100.0 * decided_total / max(1, checked_images)))
