@@ -124,3 +124,37 @@ def test_random_architectures_and_shapes_against_the_oracle():
     print("[fuzz] {} cases ({} refused up front), {} images, {} decided ({:.0f} %)".format(
         cases, refused, checked_images, decided_total, 100.0 * decided_total / max(1, checked_images)))
     assert decided_total >= 0.5 * checked_images
+
+
+def test_random_call_sequences_replay_graphs_like_plain_launches():
+    """A random walk over shapes, streams and output options on ONE engine with hipGraph replay on (more distinct shapes than the
+    graph cache holds, so entries are evicted and re-captured; two streams with their own workspaces that grow along the way; the
+    same shape revisited with other features) against an engine that only ever launches plainly: every call bit-identical."""
+    from openviic_amd.engine import CaptionEngine
+    from helpers import TINY, tiny_case
+    from openviic_amd.utils.synthetic import synthetic_features
+    lib = native.load()
+    rng = random.Random(int(os.environ.get("OVC_FUZZ_SEED", "20261004")) + 7)
+    cfg, vocab, sd, _, _ = tiny_case("meshed_memory_transformer")
+    model = device_model(cfg, vocab, sd)
+    graphed, plain = CaptionEngine(model), CaptionEngine(model)
+    graphed.use_graph, plain.use_graph = True, False
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    shapes = [(B, N, k) for B in (1, 2, 3, 5) for N in (1, 4, 7, 9, 16) for k in (1, 2, 3)]          # 60 shapes > OVC_GRAPH_CACHE_MAX
+    calls = int(os.environ.get("OVC_FUZZ_CASES", "40")) * 6
+    peak = 0
+    for call in range(calls):
+        B, N, k = rng.choice(shapes[:12]) if rng.random() < 0.5 else rng.choice(shapes)             # a hot set plus a long tail
+        feats = synthetic_features(B, N, TINY["d_feature"], seed=rng.randint(0, 5), ragged=True).cuda()
+        out_size = rng.choice([1, k])
+        probs = rng.random() < 0.15
+        stream = rng.choice(streams)
+        with torch.no_grad(), torch.cuda.stream(stream):
+            got = graphed.beam_search(feats, None, B, k, out_size=out_size, return_probs=probs)
+            want = plain.beam_search(feats, None, B, k, out_size=out_size, return_probs=probs)
+        stream.synchronize()
+        for g_t, w_t in zip(got, want):
+            assert torch.equal(g_t, w_t), "call {}: B={} N={} k={} out_size={} return_probs={}".format(call, B, N, k, out_size, probs)
+        peak = max(peak, lib.ovc_graph_cache_size())
+    assert 0 < peak <= int(os.environ.get("OVC_GRAPH_CACHE_MAX", "24"))
+    graphed.release(); plain.release()
