@@ -158,3 +158,48 @@ def test_random_call_sequences_replay_graphs_like_plain_launches():
         peak = max(peak, lib.ovc_graph_cache_size())
     assert 0 < peak <= int(os.environ.get("OVC_GRAPH_CACHE_MAX", "24"))
     graphed.release(); plain.release()
+
+
+def test_random_dual_collaborative_encoders_against_the_oracle():
+    """the dual-collaborative (DLCT) embedding + encoder on random sizes -- region counts, grid sizes
+    (n + g*g keys up to 128), feature widths, head shapes, layers, both box embeddings -- against ``oracle/dlct.py``: the five
+    masks bit-exact, the encoder output by its relative L2 error (its geometry bias is the object-relation one, see above)."""
+    from helpers import dlct_case
+    from openviic_amd.builders import build_encoder, build_vision_embedding
+    from oracle.dlct import OracleDualEncoder
+    rng = random.Random(int(os.environ.get("OVC_FUZZ_SEED", "20261004")) + 13)
+    cases = max(4, int(os.environ.get("OVC_FUZZ_CASES", "40")) // 4)
+    for case in range(cases):
+        heads, d_kv = rng.choice([(2, 32), (4, 16), (4, 32), (8, 8), (8, 16), (2, 64), (1, 64)])
+        trig = rng.random() < 0.5
+        d_model = heads * 8 * rng.randint(1, 4) if trig else 32 * rng.randint(1, 6)      # trigonometric: d_model / heads a multiple of 8
+        if d_model % 32:
+            d_model = 32 * (d_model // 32 + 1) if not trig else d_model
+        grid = rng.randint(1, 7)
+        shape = dict(B=rng.randint(1, 4), n_regions=rng.randint(2, min(60, 128 - grid * grid)), grid=grid,
+                     d_region=4 * rng.randint(2, 30), d_grid=4 * rng.randint(2, 30), d_model=d_model, heads=heads, d_kv=d_kv,
+                     d_ff=4 * rng.randint(4, 64), layers=rng.randint(1, 3))
+        what = "case {}: trig={} {}".format(case, trig, shape)
+        if trig and (d_model % heads or (d_model // heads) % 8):
+            continue
+        emb_cfg, enc_cfg, emb_sd, enc_sd, inputs = dlct_case(trig, shape, input_seed=100 + case)
+        orc = OracleDualEncoder(enc_cfg, emb_sd, enc_sd)
+        region, region_boxes, grid_f, grid_boxes = inputs
+        (orf, orm), (ogf, ogm), (or2a, og2a) = orc.embed(region, region_boxes, grid_f, grid_boxes)
+        want, want_mask = orc.encode(orf, region_boxes, orm, or2a, ogf, grid_boxes, ogm, og2a)
+        emb, enc = build_vision_embedding(emb_cfg).eval(), build_encoder(enc_cfg).eval()
+        emb.load_state_dict(emb_sd)
+        enc.load_state_dict(enc_sd)
+        emb, enc = emb.to("cuda"), enc.to("cuda")
+        try:
+            with torch.no_grad():
+                (rf, rm), (gf, gm), (r2a, g2a) = emb(*(t.to("cuda") for t in inputs))
+                out, mask = enc(rf, region_boxes.to("cuda"), rm, r2a, gf, grid_boxes.to("cuda"), gm, g2a)
+        except Exception as error:
+            raise AssertionError("{}: {}".format(what, error)) from error
+        assert torch.equal(rm.cpu(), orm) and torch.equal(gm.cpu(), ogm), what
+        assert torch.equal(r2a.cpu(), or2a) and torch.equal(g2a.cpu(), og2a) and torch.equal(mask.cpu(), want_mask), what
+        got, ref = out.cpu().numpy(), want.numpy()
+        keep = np.isfinite(ref).all(axis=-1)                        # a row whose every key is masked is NaN in the reference
+        err = np.linalg.norm(got[keep] - ref[keep]) / max(np.linalg.norm(ref[keep]), 1e-12)
+        assert err < (3e-4 if trig else 5e-5), "{}: relative L2 error {:.2e}".format(what, err)
