@@ -11,6 +11,8 @@ Two kinds of comparison:
   reference decision margin is below fp32 noise can legitimately flip; ids are asserted exactly for every image
   whose smallest margin exceeds ``MARGIN``, and each test prints the decided / identical fractions it saw.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -525,6 +527,30 @@ def test_concurrent_streams_give_the_single_stream_result():
     for outs in rounds:
         for (ids, logp), (want_ids, want_logp) in zip(outs, alone):
             assert torch.equal(ids, want_ids) and torch.equal(logp, want_logp)
+
+
+@pytest.mark.parametrize("variant", ["standard_transformer", "meshed_memory_transformer"])
+def test_repeated_decodes_under_load_are_bit_identical(variant):
+    """A soak for races: four streams, each replaying its own batch of 64 images 25 times while the other three keep the chip
+    busy with theirs (the headline mode's co-residency: GEMM tiles of one batch share CUs with another batch's attention and
+    selection kernels; OVC_SOAK_ROUNDS for longer runs).  Every one of the 100 results must equal, bit for bit, what its batch decodes to alone -- a missing
+    barrier, a workspace shared across streams or an order-dependent reduction would show up as a flipped low-order bit."""
+    cfg, vocab, sd, feats, boxes = full_case(variant, 256)
+    model = device_model(cfg, vocab, sd)
+    chunks = [feats[i * 64:(i + 1) * 64].cuda() for i in range(4)]
+    with torch.no_grad():
+        alone = [model.beam_search(batch(c), batch_size=64, beam_size=5) for c in chunks]
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream() for _ in range(4)]
+    results = []
+    with torch.no_grad():
+        for _ in range(int(os.environ.get("OVC_SOAK_ROUNDS", "25"))):
+            for i, (s, c) in enumerate(zip(streams, chunks)):
+                with torch.cuda.stream(s):
+                    results.append((i, model.beam_search(batch(c), batch_size=64, beam_size=5)))
+    torch.cuda.synchronize()
+    for i, (ids, logp) in results:
+        assert torch.equal(ids, alone[i][0]) and torch.equal(logp, alone[i][1])
 
 
 def test_invalid_requests_fail_loudly():
