@@ -311,6 +311,7 @@ int ovc_graph_cache_size(void);
  * ovc_profile_kernel_name(tiling)); with ksplit > 1, y receives the ksplit raw partial products [ksplit][M][N];
  * `iters` back-to-back launches. */
 int ovc_debug_force_gemm_tiling(int tiling);
+int ovc_debug_clear_tuning(void);                 /* forget every remembered tiling (tests) */
 int ovc_debug_linear_tiling(const float* x, int K, const float* W, const float* bias, float* y, int M, int N,
                             int tiling, int ksplit, int iters, ovc_stream stream);
 

@@ -659,6 +659,13 @@ extern "C" int ovc_debug_rebind_device(int device) {
     return OVC_OK;
 }
 
+// Forget every measured tiling (tests: a measurement-count assertion must not depend on what earlier tests left in the table).
+extern "C" int ovc_debug_clear_tuning(void) {
+    std::lock_guard<std::mutex> lock(g_tuned_mutex);
+    g_tuned.clear();
+    return OVC_OK;
+}
+
 extern "C" int ovc_debug_force_gemm_tiling(int tiling) {
     if (tiling < -1 || tiling >= kNumTilings) return OVC_EINVAL;
     g_forced_tiling.store(tiling);

@@ -232,8 +232,10 @@ class CaptionEngine:
     def tune(self, B, N, k):
         """Time the GEMM tilings of each of the engine's (shape, K-order class) once and let the library remember the
         fastest (synchronises; ~0.2 s).  Speed only: all tilings of a class give the same bits.  Shapes for which the
-        library already holds an entry with M within a factor of two (another region count or batch size) are not
-        measured again, so batches with varying N never wait here after the first one."""
+        library already holds a MEASURED entry with M within a factor of two (another region count or batch size) borrow its
+        choice and are not measured, so batches whose N varies inside such a range never wait here after the first one (a
+        shape that borrowed leaves no entry of its own: a later shape beyond the factor of two of every measured M is measured
+        once more)."""
         objective = int(self.desc.tune_objective)
         key = (B, N, k)
         if key in self._tuned:

@@ -101,6 +101,7 @@ SIGNATURES = {
     "ovc_graph_cache_drop_workspace": (c_int, [c_void_p]),
     "ovc_graph_cache_size": (c_int, []),
     "ovc_debug_force_gemm_tiling": (c_int, [c_int]),
+    "ovc_debug_clear_tuning": (c_int, []),
     "ovc_debug_linear_tiling": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "ovc_debug_vocab_select_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "ovc_debug_vocab_select": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p,
