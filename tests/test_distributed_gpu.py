@@ -5,6 +5,7 @@ images on the last rank, and that a shard decodes exactly as it does inside the 
 """
 import os
 import socket
+import time
 
 import numpy as np
 import pytest
@@ -47,7 +48,14 @@ def _worker(rank, world, port, total, out_dir):
 
 @pytest.mark.parametrize("world,total", [(2, 24), (3, 20)])
 def test_ranks_sharing_the_gpu_decode_their_shards_like_the_whole_batch(tmp_path, world, total):
-    mp.spawn(_worker, args=(world, _free_port(), total, str(tmp_path)), nprocs=world, join=True)
+    ctx = mp.spawn(_worker, args=(world, _free_port(), total, str(tmp_path)), nprocs=world, join=False)
+    deadline = time.time() + 300                       # a rank that never reaches the rendezvous must not hang the suite
+    while not ctx.join(timeout=5):
+        if time.time() > deadline:
+            for proc in ctx.processes:
+                if proc.is_alive():
+                    proc.terminate()
+            pytest.fail("ranks did not finish within 300 s")
     cfg, vocab, sd, feats, _ = full_case("standard_transformer", total, ragged=True)
     model = device_model(cfg, vocab, sd)
     with torch.no_grad():
