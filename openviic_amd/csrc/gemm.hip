@@ -38,6 +38,7 @@
 //   * Seventeen tilings (128x128 ... 32x32; K tile 16, 32 or 64); ovc_gemm_tune measures the ones of the requested
 //     class per shape, a cost model covers shapes that were never measured.
 #include <atomic>
+#include <type_traits>
 #include <mutex>
 #include <vector>
 
@@ -353,17 +354,11 @@ __global__ __launch_bounds__(256, (min_waves_per_simd<BM, BN, BK, NC>())) void g
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[c][i][j][r] = 0.f;
 
-    load_tile(0);
-    store_tile(0);
-    __syncthreads();
-
     const int frag_row = lane & 31;
     const int frag_k = (lane >> 5) * 4;
 
-    for (int kt = 0; kt < nkt; ++kt) {
-        const int buf = Cfg::kBufs == 2 ? (kt & 1) : 0;
-        if (kt + 1 < nkt) load_tile(kt + 1);
-
+    // the MFMA block of one K tile (LDS buffer `buf`)
+    auto compute_tile = [&](int buf) {
         const float* a_base = lds + buf * kBufFloats + (wm * Cfg::kWaveM + frag_row) * LDT + frag_k;
         const float* b_base = lds + buf * kBufFloats + (BM + wn * Cfg::kWaveN + frag_row) * LDT + frag_k;
         // 8-deep k-groups of this K tile, in order.  One chain: every group goes to accumulator set 0.  Four chains:
@@ -394,12 +389,89 @@ __global__ __launch_bounds__(256, (min_waves_per_simd<BM, BN, BK, NC>())) void g
                         acc[set][i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][s], b[j][s], acc[set][i][j], 0, 0, 0);
             __builtin_amdgcn_s_setprio(0);
         }
+    };
 
-        if (kt + 1 < nkt) {
-            if (Cfg::kBufs == 1) __syncthreads();
-            store_tile(Cfg::kBufs == 2 ? (buf ^ 1) : 0);
+    // Prefetch distance two for the tiles of up to 64 x 64 (round 3): the tile AFTER next is requested before this tile's MFMA block,
+    // into a second set of staging registers, so that a K iteration no longer has to cover a whole L2 round trip -- with 16 K
+    // tiles or fewer per output tile and an MFMA block of a fraction of a microsecond these loops were chains of load latencies
+    // (steady state 0.94 us per 64-deep K tile where the matrix pipe needs 0.53).  Same instructions in the same order on every
+    // accumulator: the bits do not change.  Measured: cross-q 12.9 -> 11.6 us, output projection 11.5 -> 10.6, q|k|v 22.6 -> 21.7,
+    // FFN 27.6 -> 26.6, encoder q|k|v 160 -> 155, vocabulary^T 109.9 -> 106.3; captions/s +1.3 % (four streams), +2.7 % (one).
+    // Not for the larger tiles (their second register set costs a resident workgroup: 128 x 64 160.9 -> 166.4 us) nor for the
+    // K-tile-64 instances with chains in two waves (96-register cap: 13 spilled).
+#ifdef OVC_NO_PF2                   // A/B builds only: tools/ab_bench.sh against a library compiled with -DOVC_NO_PF2
+    constexpr bool kPF2 = false;
+#else
+    constexpr bool kPF2 = BM * BN <= 64 * 64 && Cfg::kBufs == 1 && !(WK == 2 && BK == 64);
+#endif
+    constexpr int kDepth = 2;       // staging register sets = tiles requested ahead (3 and 4 measured: slower on every shape --
+                                    // 32x32 cross-q 11.9 / 12.6 / 12.5 us, 64x64 vocabulary^T 105.7 / 110.2 / 113.3 -- even without spills)
+    bool done = false;
+    if constexpr (kPF2) {
+        if (!k_tail && p.K2 == 0 && !row_sums && nkt >= kDepth) {
+            f32x4 sa[kDepth][Cfg::kLoadA], sb[kDepth][Cfg::kLoadB];
+            auto load_set = [&](int kt, auto set_tag) {
+                constexpr int S = decltype(set_tag)::value;
+                const int k0 = kbase + kt * BK;
+#pragma unroll
+                for (int i = 0; i < Cfg::kLoadA; ++i)
+                    sa[S][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_a1, off_a1[i], k0 * 4, 0));
+#pragma unroll
+                for (int i = 0; i < Cfg::kLoadB; ++i)
+                    sb[S][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, off_w[i], k0 * 4, 0));
+            };
+            auto store_set = [&](auto set_tag) {
+                constexpr int S = decltype(set_tag)::value;
+                const int kq = tid % kVecPerRow;
+#pragma unroll
+                for (int i = 0; i < Cfg::kLoadA; ++i)
+                    *reinterpret_cast<f32x4*>(lds + (tid / kVecPerRow + i * kRowsPerPass) * LDT + kq * 4) = sa[S][i];
+#pragma unroll
+                for (int i = 0; i < Cfg::kLoadB; ++i)
+                    *reinterpret_cast<f32x4*>(lds + (BM + tid / kVecPerRow + i * kRowsPerPass) * LDT + kq * 4) = sb[S][i];
+            };
+            // tile j waits in register set j % kDepth.  One step: tile kt is in LDS and its set is free -> request tile kt + kDepth
+            // into it, run tile kt's MFMA block, move tile kt + 1 (requested kDepth - 1 blocks ago) to LDS.
+            auto step = [&](int kt, auto cur_tag) {
+                constexpr int C = decltype(cur_tag)::value;
+                if (kt + kDepth < nkt) load_set(kt + kDepth, cur_tag);
+                compute_tile(0);
+                if (kt + 1 < nkt) {
+                    __syncthreads();
+                    store_set(std::integral_constant<int, (C + 1) % kDepth>{});
+                    __syncthreads();
+                }
+            };
+            load_set(0, std::integral_constant<int, 0>{});
+            if constexpr (kDepth > 1) load_set(1, std::integral_constant<int, 1 % kDepth>{});
+            if constexpr (kDepth > 2) load_set(2, std::integral_constant<int, 2 % kDepth>{});
+            if constexpr (kDepth > 3) load_set(3, std::integral_constant<int, 3 % kDepth>{});
+            store_set(std::integral_constant<int, 0>{});
+            __syncthreads();
+            for (int kt = 0; kt < nkt; kt += kDepth) {
+                step(kt, std::integral_constant<int, 0>{});
+                if constexpr (kDepth > 1) { if (kt + 1 < nkt) step(kt + 1, std::integral_constant<int, 1 % kDepth>{}); }
+                if constexpr (kDepth > 2) { if (kt + 2 < nkt) step(kt + 2, std::integral_constant<int, 2 % kDepth>{}); }
+                if constexpr (kDepth > 3) { if (kt + 3 < nkt) step(kt + 3, std::integral_constant<int, 3 % kDepth>{}); }
+            }
+            __syncthreads();
+            done = true;
         }
+    }
+    if (!done) {
+        load_tile(0);
+        store_tile(0);
         __syncthreads();
+        for (int kt = 0; kt < nkt; ++kt) {
+            const int buf = Cfg::kBufs == 2 ? (kt & 1) : 0;
+            if (kt + 1 < nkt) load_tile(kt + 1);
+            compute_tile(buf);
+            if (kt + 1 < nkt) {
+                if (Cfg::kBufs == 1) __syncthreads();
+                store_tile(Cfg::kBufs == 2 ? (buf ^ 1) : 0);
+            }
+            __syncthreads();
+        }
     }
 
     if (row_sums) {
