@@ -398,7 +398,8 @@ __global__ __launch_bounds__(256, (min_waves_per_simd<BM, BN, BK, NC>())) void g
     // accumulator: the bits do not change.  Measured: cross-q 12.9 -> 11.6 us, output projection 11.5 -> 10.6, q|k|v 22.6 -> 21.7,
     // FFN 27.6 -> 26.6, encoder q|k|v 160 -> 155, vocabulary^T 109.9 -> 106.3; captions/s +1.3 % (four streams), +2.7 % (one).
     // Not for the larger tiles (their second register set costs a resident workgroup: 128 x 64 160.9 -> 166.4 us) nor for the
-    // K-tile-64 instances with chains in two waves (96-register cap: 13 spilled).
+    // K-tile-64 instances with chains in two waves (96-register cap: 13 spilled).  With two LDS buffers on top (one barrier per
+    // K tile instead of two) every shape got slower again (encoder q|k|v 154.6 -> 163.8 us): LDS residency beats the barrier.
 #ifdef OVC_NO_PF2                   // A/B builds only: tools/ab_bench.sh against a library compiled with -DOVC_NO_PF2
     constexpr bool kPF2 = false;
 #else
