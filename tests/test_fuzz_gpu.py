@@ -86,9 +86,12 @@ def test_random_architectures_and_shapes_against_the_oracle():
             # rounding-level change of fc_g's output moves the bias by O(1), and the trigonometric embedding takes sin / cos of
             # angles up to ~700 rad (one ulp of the angle: 6e-5).  Any two fp32 implementations differ in a few elements there,
             # so this encoder is held to a norm: relative L2 error of the whole output; element-wise only a coarse sanity bound
-            # (1 element in 70 000 was seen 2e-3 off in 3 000 cases).
+            # (1 element in 70 000 was seen 2e-3 off in 3 000 cases).  With the trigonometric embedding the box-relation weights
+            # themselves differ by up to 4e-5 between two fp32 implementations (log-ratios up to 6.9 times 100 times the frequency:
+            # one ulp of the logarithm is 5e-5 in the angle), and a weight of 1e-3 next to the ReLU's zero then moves the bias by
+            # 0.1: relative L2 errors up to 1.4e-3 were seen (1 case in 4 000); the bound is 3e-3.
             err = np.linalg.norm(got_enc - ref_enc) / max(np.linalg.norm(ref_enc), 1e-12)
-            assert err < (3e-4 if trig else 5e-5), "{}: relative L2 error {:.2e}".format(what, err)
+            assert err < (3e-3 if trig else 5e-5), "{}: relative L2 error {:.2e}".format(what, err)
             np.testing.assert_allclose(got_enc, ref_enc, rtol=5e-2, atol=2e-2, err_msg=what)
         else:
             np.testing.assert_allclose(got_enc, ref_enc, rtol=2e-4, atol=2e-5, err_msg=what)
@@ -203,4 +206,4 @@ def test_random_dual_collaborative_encoders_against_the_oracle():
         got, ref = out.cpu().numpy(), want.numpy()
         keep = np.isfinite(ref).all(axis=-1)                        # a row whose every key is masked is NaN in the reference
         err = np.linalg.norm(got[keep] - ref[keep]) / max(np.linalg.norm(ref[keep]), 1e-12)
-        assert err < (3e-4 if trig else 5e-5), "{}: relative L2 error {:.2e}".format(what, err)
+        assert err < (3e-3 if trig else 5e-5), "{}: relative L2 error {:.2e}".format(what, err)
