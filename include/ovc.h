@@ -42,6 +42,7 @@ typedef void* ovc_stream;              /* a hipStream_t (NULL = the null stream)
 #define OVC_MAX_LEVELS    4
 #define OVC_MAX_BEAM      8
 #define OVC_MAX_SEGMENTS  8
+#define OVC_MAX_REGIONS   1024         /* regions (or grid cells) per image the engine accepts */
 
 /* library / build identification ------------------------------------------------------ */
 int         ovc_abi_version(void);             /* bumps when a struct layout changes     */
@@ -79,7 +80,10 @@ int ovc_layer_norm(const float* x, const float* residual, const float* gamma, co
  *   mask element (b,iq,ik) is mask[b*mask_sb + iq*mask_sq + ik] (mask_sq = 0 broadcasts over
  *   queries), NULL = no mask.  Memory slots (mem_k [m,h*dk], mem_v [m,h*dv], may be NULL):
  *   m extra keys mem_scale_k*mem_k and values mem_scale_v*mem_v appended after the nk real
- *   keys and never masked.  nk + m <= 128; dk, dv multiples of 4 and <= 64.
+ *   keys and never masked.  dk, dv multiples of 4 and <= 64; any nq, nk, m (the reference has no limit either:
+ *   attentions.py:44-58): up to 128 keys (nk + m) and 128 queries the scores of a query stay in registers; beyond that the
+ *   keys pass in tiles of 128, ascending, under an online softmax (a fixed order: results depend on the operands only).
+ *   A query whose keys are all masked gets NaN, as torch.softmax over a row of -inf does.
  * Replaces attentions.py:51-55 (plain), :102-111 (geometry), :171-183 (memory). */
 int ovc_attention(const float* q, const float* k, const float* v, int b, int nq, int nk, int h,
                   int dk, int dv, const uint8_t* mask, long mask_sb, long mask_sq,
@@ -201,7 +205,9 @@ typedef struct {
 
 /* Sizes the engine accepts (anything else: ovc_workspace_bytes returns 0, the calls OVC_EINVAL) -- the
  * reference itself has no such limits, these are the template instances built so far:
- *   regions N <= 128;  beam k <= OVC_MAX_BEAM (8);  max_len <= 64;  any vocabulary (above 16384 words the
+ *   regions N <= OVC_MAX_REGIONS (1024), memory slots on top of them without a limit of their own (N + memory <= 128
+ *   runs on the register-resident attention instances, anything larger on the key-tiled ones -- e.g. the shipped
+ *   meshed_memory_transformer.yaml, MEMORY: 40, with 89..1024 regions);  beam k <= OVC_MAX_BEAM (8);  max_len <= 64;  any vocabulary (above 16384 words the
  *   selection streams each row k + 2 times instead of holding it in registers);
  *   d_model <= 2048 (multiple of 4; of 32 for models with AoA gates or the meshed decoder, whose products over a
  *   concatenated input read the two halves from their own buffers);  d_k == d_v in {4, 8, 16, 32, 64}, heads <= 32,

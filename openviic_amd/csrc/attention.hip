@@ -334,6 +334,180 @@ __global__ __launch_bounds__(256) void attention_regs_kernel(AttnArgs p) {
     }
 }
 
+// -------------------------------------------------------------------------------------------------
+// attention_tiled_kernel: the same operator without a limit on the number of keys or queries (round 4).  The reference has
+// none (attentions.py:44-58 works on any nk, :158-185 appends its 40 memory slots to any nk): bottom-up feature sets carry up
+// to 100 regions per image (+ 40 slots = 140 keys), grid features 14 x 14 = 196 cells, the DLCT form regions + cells.
+//
+// One workgroup per (image, head, 128 queries), a wave per 32 queries -- the register layout of attention_regs_kernel
+// (S^T = K Q^T with the query on the lane, O^T = V^T P^T with the probabilities as the B operand) -- but the keys pass
+// through LDS in tiles of 128, in ascending order, under an online softmax: per query a running maximum M and a running sum
+// L of exp(s - M); a tile whose maximum raises M rescales L and the output accumulators by exp(M_old - M_new), which is a
+// per-lane scalar here because a lane's accumulator registers all belong to ITS query.  The tile order is fixed, so a result
+// depends on nothing but the operands (no timing, no batch size).  Fully masked rows end with L = 0 and give 0 / 0 = NaN,
+// as the reference's softmax over a row of -inf does.  Numerics vs the kernels above: the division by the softmax sum
+// happens once at the end instead of per probability (~1 ulp per output); shapes with nk + m <= 128 and nq <= 128 never come
+// here, so nothing that ran before round 4 changes a bit.
+// KG = 8-deep d groups of Q.K (dk <= 8 KG); DVT = 32-wide tiles of d_v.
+// -------------------------------------------------------------------------------------------------
+template <int KG, int DVT>
+__global__ __launch_bounds__(256) void attention_tiled_kernel(AttnArgs p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int NKT = 4, kRows = NKT * 32;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int qt = blockIdx.x % p.qtiles;
+    const int hd = (blockIdx.x / p.qtiles) % p.h;
+    const int b = blockIdx.x / (p.qtiles * p.h);
+    const int nkt = p.nk + p.m;
+    float* Ks = lds;                          // [128][68]; doubles as the output staging area at the end
+    float* Vs = Ks + kRows * kLdQK;           // [128][68]
+
+    const int qi = lane & 31, half = lane >> 5;
+    const int gq = qt * kRows + wave * 32 + qi;                 // this lane's query
+    const bool q_ok = gq < p.nq;
+    const bool wave_live = qt * kRows + wave * 32 < p.nq;       // wave-uniform: waves past the last query only stage
+    f32x4 qf[KG];
+    {
+        const float* qrow = p.q + ((size_t)b * p.nq + min(gq, p.nq - 1)) * (p.h * p.dk) + hd * p.dk;
+#pragma unroll
+        for (int kk = 0; kk < KG; ++kk) {
+            const int d = 8 * kk + 4 * half;
+            qf[kk] = *reinterpret_cast<const f32x4*>(qrow + min(d, p.dk - 4));
+            if (!q_ok || d >= p.dk) qf[kk] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    const float inv_scale = sqrtf((float)p.dk);
+    const uint8_t* mrow = p.mask ? p.mask + (size_t)b * p.mask_sb + (size_t)min(gq, p.nq - 1) * p.mask_sq : nullptr;
+    const float* grow = p.geometry ? p.geometry + (((size_t)b * p.h + hd) * p.nq + min(gq, p.nq - 1)) * p.nk : nullptr;
+
+    float m_run = -INFINITY, l_run = 0.f;
+    f32x16 ot[DVT];
+#pragma unroll
+    for (int t = 0; t < DVT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ot[t][r] = 0.f;
+
+    for (int k0 = 0; k0 < nkt; k0 += kRows) {
+        // ---- this tile's K, V rows -> LDS (zero-filled past the last key); every load issued before the first LDS store ------
+        {
+            const int c4 = tid & 15, col = c4 * 4, r0 = tid >> 4;
+            constexpr int kPasses = kRows / 16;
+            f32x4 kv[kPasses], vv[kPasses];
+#pragma unroll
+            for (int i = 0; i < kPasses; ++i) {
+                const int kr = k0 + r0 + 16 * i;
+                const bool real = kr < p.nk, slot = !real && kr < nkt;
+                const int mr = min(max(kr - p.nk, 0), max(p.m - 1, 0));
+                const float* ks = slot ? p.mem_k + (size_t)mr * (p.h * p.dk) + hd * p.dk
+                                       : p.k + ((size_t)b * p.nk + (real ? kr : 0)) * (p.h * p.dk) + hd * p.dk;
+                const float* vs = slot ? p.mem_v + (size_t)mr * (p.h * p.dv) + hd * p.dv
+                                       : p.v + ((size_t)b * p.nk + (real ? kr : 0)) * (p.h * p.dv) + hd * p.dv;
+                kv[i] = *reinterpret_cast<const f32x4*>(ks + min(col, p.dk - 4));
+                vv[i] = *reinterpret_cast<const f32x4*>(vs + min(col, p.dv - 4));
+            }
+#pragma unroll
+            for (int i = 0; i < kPasses; ++i) {
+                const int r = r0 + 16 * i, kr = k0 + r;
+                const bool real = kr < p.nk, slot = !real && kr < nkt;
+                f32x4 kx = kv[i], vx = vv[i];
+                if (slot) { kx = kx * p.mem_scale_k; vx = vx * p.mem_scale_v; }
+                if ((!real && !slot) || col >= p.dk) kx = f32x4{0.f, 0.f, 0.f, 0.f};
+                if ((!real && !slot) || col >= p.dv) vx = f32x4{0.f, 0.f, 0.f, 0.f};
+                *reinterpret_cast<f32x4*>(Ks + r * kLdQK + col) = kx;
+                *reinterpret_cast<f32x4*>(Vs + r * kLdQK + col) = vx;
+            }
+        }
+        __syncthreads();
+
+        if (wave_live) {
+            // ---- S^T = K Q^T for the tile's 128 keys ---------------------------------------------------------------------------
+            f32x16 st[NKT];
+#pragma unroll
+            for (int tk = 0; tk < NKT; ++tk)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) st[tk][r] = 0.f;
+#pragma unroll
+            for (int kk = 0; kk < KG; ++kk) {
+                f32x4 kf[NKT];
+#pragma unroll
+                for (int tk = 0; tk < NKT; ++tk) kf[tk] = *reinterpret_cast<const f32x4*>(Ks + (tk * 32 + qi) * kLdQK + 8 * kk + 4 * half);
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int tk = 0; tk < NKT; ++tk) st[tk] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[tk][s], qf[kk][s], st[tk], 0, 0, 0);
+            }
+            // ---- scale, mask, geometry bias; the tile's maximum for this lane's query ----------------------------------------
+            float mx = -INFINITY;
+#pragma unroll
+            for (int tk = 0; tk < NKT; ++tk)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int kj = k0 + tk * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    float s = st[tk][r] / inv_scale;
+                    if (kj >= nkt) {
+                        s = -INFINITY;
+                    } else if (kj < p.nk) {
+                        if (mrow && mrow[kj]) s = -INFINITY;
+                        if (grow) s = logf(fmaxf(grow[kj], 1e-6f)) + s;
+                    }
+                    st[tk][r] = s;
+                    mx = fmaxf(mx, s);
+                }
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float m_new = fmaxf(m_run, mx);
+            const bool none = m_new == -INFINITY;                    // every key so far masked: nothing to add, nothing to rescale
+            const float alpha = none ? 1.f : expf(m_run - m_new);    // m_run = -inf, m_new finite: 0 (L and O are 0 anyway)
+            float sum = 0.f;
+#pragma unroll
+            for (int tk = 0; tk < NKT; ++tk)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float e = none ? 0.f : expf(st[tk][r] - m_new);
+                    st[tk][r] = e;
+                    sum += e;
+                }
+            sum += __shfl_xor(sum, 32, 64);
+            l_run = l_run * alpha + sum;
+            m_run = m_new;
+#pragma unroll
+            for (int t = 0; t < DVT; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) ot[t][r] *= alpha;
+            // ---- O^T += V^T E^T -------------------------------------------------------------------------------------------------
+#pragma unroll
+            for (int tk = 0; tk < NKT; ++tk)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float* vrow = Vs + (tk * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * kLdQK + qi;
+#pragma unroll
+                    for (int t = 0; t < DVT; ++t) ot[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(vrow[t * 32], st[tk][r], ot[t], 0, 0, 0);
+                }
+        }
+        __syncthreads();                                             // every wave is done with this tile's images
+    }
+    if (!wave_live) return;
+
+    // ---- normalise; accumulator (dv on registers, query on the lane) -> LDS [query][dv] -> whole rows to memory -----------------
+    float* Os = Ks + wave * 32 * kLdQK;
+#pragma unroll
+    for (int t = 0; t < DVT; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            *reinterpret_cast<f32x4*>(Os + qi * kLdQK + t * 32 + 8 * j + 4 * half) =
+                f32x4{ot[t][4 * j] / l_run, ot[t][4 * j + 1] / l_run, ot[t][4 * j + 2] / l_run, ot[t][4 * j + 3] / l_run};
+    {
+        const int c4 = lane & 15, col = c4 * 4;
+#pragma unroll
+        for (int pass = 0; pass < 8; ++pass) {
+            const int row = pass * 4 + (lane >> 4);
+            const int oq = qt * kRows + wave * 32 + row;
+            if (oq < p.nq && col < p.dv)
+                *reinterpret_cast<f32x4*>(p.out + ((size_t)b * p.nq + oq) * (p.h * p.dv) + hd * p.dv + col) =
+                    *reinterpret_cast<const f32x4*>(Os + row * kLdQK + col);
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int ovc_attention(const float* q, const float* k, const float* v, int b, int nq, int nk, int h,
@@ -343,7 +517,7 @@ extern "C" int ovc_attention(const float* q, const float* k, const float* v, int
     if (!q || !k || !v || !out || b <= 0 || nq <= 0 || nk <= 0 || h <= 0) return OVC_EINVAL;
     if (const int rc = ovc_device_guard()) return rc;      // kernel attributes below are raised once per process
     if (dk <= 0 || dv <= 0 || (dk & 3) || (dv & 3) || dk > 64 || dv > 64) return OVC_EINVAL;
-    if (m < 0 || (m > 0 && (!mem_k || !mem_v)) || nk + m > 128) return OVC_EINVAL;
+    if (m < 0 || (m > 0 && (!mem_k || !mem_v))) return OVC_EINVAL;
     if (!ovc_aligned16(q) || !ovc_aligned16(k) || !ovc_aligned16(v)) return OVC_EINVAL;
     if (m > 0 && (!ovc_aligned16(mem_k) || !ovc_aligned16(mem_v))) return OVC_EINVAL;
     AttnArgs p{};
@@ -382,6 +556,27 @@ extern "C" int ovc_attention(const float* q, const float* k, const float* v, int
             return OVC_OK;
         }
     }
+    // More than 128 keys (real + memory slots): the key-tiled kernel with an online softmax, any nq and nk.
+    if (nk + m > 128) {
+        const int hmax = dk > dv ? dk : dv;
+        p.qtiles = (nq + 127) / 128;
+        const size_t bytes = sizeof(float) * (size_t)(2 * 128) * kLdQK;
+        const dim3 grid(b * h * p.qtiles), block(256);
+#define OVC_ATT_TILED(KG, DVT)                                                                                        \
+    do {                                                                                                              \
+        static std::once_flag once;                                                                                   \
+        std::call_once(once, [] {                                                                                     \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attention_tiled_kernel<KG, DVT>),                \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);                         \
+        });                                                                                                           \
+        hipLaunchKernelGGL((attention_tiled_kernel<KG, DVT>), grid, block, bytes, ovc_hip_stream(stream), p);         \
+    } while (0)
+        if (hmax <= 16) OVC_ATT_TILED(2, 1); else if (hmax <= 32) OVC_ATT_TILED(4, 1); else OVC_ATT_TILED(8, 2);
+#undef OVC_ATT_TILED
+        OVC_RETURN_IF_LAUNCH_FAILED();
+        return OVC_OK;
+    }
+    // nq > 128 with at most 128 keys: the LDS-score kernel over 64-query tiles
     const size_t lds_bytes = sizeof(float) * ((size_t)kQTile * kLdQK + 2 * (size_t)p.nkp * kLdQK + (size_t)kQTile * (p.nkp + 4));
     static std::once_flag attr_once;
     std::call_once(attr_once, [] {
@@ -839,53 +1034,169 @@ __global__ __launch_bounds__(256) void decode_cross_attention_mfma_kernel(Decode
     }
 }
 
-// Head sizes 4 and 8 (not multiples of the 16-deep MFMA k block): K/V of one (image, head) staged in LDS, VALU dots.
+// The same kernel for more than 128 regions (round 4; the reference has no limit): the keys pass through the wave in chunks
+// of 64 (four 16-key tiles), in ascending order, under an online softmax -- a running maximum and sum per beam column, the
+// output accumulators rescaled by exp(M_old - M_new) when a chunk raises the maximum (a per-lane scalar: a lane's accumulator
+// registers all belong to ITS beam).  Fixed chunk order: results depend on the operands only.  N <= 128 never comes here.
+template <int SB>
+__global__ __launch_bounds__(256) void decode_cross_attention_tiled_kernel(DecodeCrossArgs p) {
+    constexpr int NT = 4;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = blockIdx.x, hd = min((int)blockIdx.y * 4 + wave, p.heads - 1), lvl = blockIdx.z;
+    const bool live = (int)blockIdx.y * 4 + wave < p.heads;
+    const int N = p.n, W = p.width;
+    const int r = lane & 15, kq = lane >> 4;
+    const float* kg = p.kx + (size_t)lvl * p.level_stride + (size_t)b * N * p.ldkv + hd * p.dk;
+    const float* vg = p.vx + (size_t)lvl * p.level_stride + (size_t)b * N * p.ldkv + hd * p.dv;
+    const float* qg = p.q + (size_t)(b * W + min(r, W - 1)) * p.ldq + hd * p.dk;
+    const uint8_t* mrow = p.encmask ? p.encmask + (size_t)b * N : nullptr;
+
+    f32x4 qf[SB];
+#pragma unroll
+    for (int S = 0; S < SB; ++S) qf[S] = *reinterpret_cast<const f32x4*>(qg + 16 * S + 4 * kq);
+    if (r >= W) {
+#pragma unroll
+        for (int S = 0; S < SB; ++S) qf[S] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const float scale_div = sqrtf((float)p.dk);
+    const int vc = 4 * min(r, (p.dv >> 2) - 1);
+    float m_run = -INFINITY, l_run = 0.f;
+    f32x4 acc[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[e] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int k0 = 0; k0 < N; k0 += 16 * NT) {
+        f32x4 kf[NT][SB];
+#pragma unroll
+        for (int T = 0; T < NT; ++T) {
+            const float* krow = kg + (size_t)min(k0 + 16 * T + r, N - 1) * p.ldkv + 4 * kq;
+#pragma unroll
+            for (int S = 0; S < SB; ++S) kf[T][S] = *reinterpret_cast<const f32x4*>(krow + 16 * S);
+        }
+        uint8_t mk[NT][4];
+#pragma unroll
+        for (int T = 0; T < NT; ++T)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) mk[T][g] = 0;
+        if (mrow) {
+#pragma unroll
+            for (int T = 0; T < NT; ++T)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) mk[T][g] = mrow[min(k0 + 16 * T + 4 * kq + g, N - 1)];
+        }
+        f32x4 st[NT];
+#pragma unroll
+        for (int T = 0; T < NT; ++T) st[T] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int S = 0; S < SB; ++S)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int T = 0; T < NT; ++T) st[T] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[T][S][e], qf[S][e], st[T], 0, 0, 0);
+        f32x4 vf[NT][4];
+#pragma unroll
+        for (int T = 0; T < NT; ++T)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                vf[T][g] = *reinterpret_cast<const f32x4*>(vg + (size_t)min(k0 + 16 * T + 4 * kq + g, N - 1) * p.ldkv + vc);
+
+        float mx = -INFINITY;
+#pragma unroll
+        for (int T = 0; T < NT; ++T)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int key = k0 + 16 * T + 4 * kq + g;
+                float s = st[T][g] / scale_div;
+                if (key >= N || mk[T][g]) s = -INFINITY;
+                st[T][g] = s;
+                mx = fmaxf(mx, s);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx);
+        const bool none = m_new == -INFINITY;
+        const float alpha = none ? 1.f : expf(m_run - m_new);
+        float sum = 0.f;
+#pragma unroll
+        for (int T = 0; T < NT; ++T)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float e = none ? 0.f : expf(st[T][g] - m_new);
+                st[T][g] = e;
+                sum += e;
+            }
+        sum += __shfl_xor(sum, 16, 64);
+        sum += __shfl_xor(sum, 32, 64);
+        l_run = l_run * alpha + sum;
+        m_run = m_new;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] = acc[e] * alpha;
+#pragma unroll
+        for (int T = 0; T < NT; ++T)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[e] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[T][g][e], st[T][g], acc[e], 0, 0, 0);
+    }
+    if (live && r < W) {
+        float* orow = p.out + (size_t)lvl * p.out_level_stride + (size_t)(b * W + r) * p.ldo + hd * p.dv;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int dvb = 16 * kq + 4 * g;
+            if (dvb < p.dv)
+                *reinterpret_cast<f32x4*>(orow + dvb) = f32x4{acc[0][g] / l_run, acc[1][g] / l_run, acc[2][g] / l_run, acc[3][g] / l_run};
+        }
+    }
+}
+
+// Head sizes 4 and 8 (not multiples of the 16-deep MFMA k block): VALU dots on LDS-staged rows.  The scores of all N keys
+// stay in LDS; K and then V of the (image, head) pass through in chunks of 128 rows, ascending, so any region count fits
+// (round 4) and the sums keep the key order of the one-shot form.
 // Exercised by tests/test_engine_gpu.py::test_unusual_dimensions_against_oracle (d_k = 8 and d_k = 4 cases).
+constexpr int kCrossChunk = 128;
 __global__ __launch_bounds__(256) void decode_cross_attention_lds_kernel(DecodeCrossArgs p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.x, hd = blockIdx.y, lvl = blockIdx.z;
     const int N = p.n, W = p.width;
-    float* Ks = lds;                         // [N][68]
-    float* Vs = Ks + N * kLdQK;              // [N][68]
-    float* qs = Vs + N * kLdQK;              // [W][64]
+    float* Xs = lds;                         // [128][68]: a chunk of K rows, later of V rows
+    float* qs = Xs + kCrossChunk * kLdQK;    // [W][64]
     float* sc = qs + W * 64;                 // [W][N]
 
     const float* kg = p.kx + (size_t)lvl * p.level_stride + (size_t)b * N * p.ldkv;
     const float* vg = p.vx + (size_t)lvl * p.level_stride + (size_t)b * N * p.ldkv;
-    {
-        const int c4 = tid & 15, r0 = tid >> 4, col = c4 * 4;
-        for (int r = r0; r < N; r += 16) {
-            f32x4 kv = {0.f, 0.f, 0.f, 0.f}, vv = {0.f, 0.f, 0.f, 0.f};
-            if (col < p.dk) kv = *reinterpret_cast<const f32x4*>(kg + (size_t)r * p.ldkv + hd * p.dk + col);
-            if (col < p.dv) vv = *reinterpret_cast<const f32x4*>(vg + (size_t)r * p.ldkv + hd * p.dv + col);
-            *reinterpret_cast<f32x4*>(Ks + r * kLdQK + col) = kv;
-            *reinterpret_cast<f32x4*>(Vs + r * kLdQK + col) = vv;
-        }
-        for (int idx = tid; idx < W * 16; idx += 256) {
-            const int i = idx >> 4, cc = (idx & 15) * 4;
-            f32x4 qv = {0.f, 0.f, 0.f, 0.f};
-            if (cc < p.dk) qv = *reinterpret_cast<const f32x4*>(p.q + (size_t)(b * W + i) * p.ldq + hd * p.dk + cc);
-            *reinterpret_cast<f32x4*>(qs + i * 64 + cc) = qv;
-        }
+    const int c4 = tid & 15, r0 = tid >> 4, col = c4 * 4;
+    for (int idx = tid; idx < W * 16; idx += 256) {
+        const int i = idx >> 4, cc = (idx & 15) * 4;
+        f32x4 qv = {0.f, 0.f, 0.f, 0.f};
+        if (cc < p.dk) qv = *reinterpret_cast<const f32x4*>(p.q + (size_t)(b * W + i) * p.ldq + hd * p.dk + cc);
+        *reinterpret_cast<f32x4*>(qs + i * 64 + cc) = qv;
     }
-    __syncthreads();
     const float scale_div = sqrtf((float)p.dk);
     const int k4n = (p.dk + 3) >> 2;
-    for (int idx = tid; idx < W * N; idx += 256) {
-        const int i = idx / N, j = idx - i * N;
-        const f32x4* kr = reinterpret_cast<const f32x4*>(Ks + j * kLdQK);
-        const f32x4* qr = reinterpret_cast<const f32x4*>(qs + i * 64);
-        float acc = 0.f;
-        for (int c = 0; c < k4n; ++c) {
-            const f32x4 a = qr[c], kk = kr[c];
-            acc += (a[0] * kk[0] + a[1] * kk[1]) + (a[2] * kk[2] + a[3] * kk[3]);
+    for (int k0 = 0; k0 < N; k0 += kCrossChunk) {
+        const int nc = min(kCrossChunk, N - k0);
+        for (int r = r0; r < nc; r += 16) {
+            f32x4 kv = {0.f, 0.f, 0.f, 0.f};
+            if (col < p.dk) kv = *reinterpret_cast<const f32x4*>(kg + (size_t)(k0 + r) * p.ldkv + hd * p.dk + col);
+            *reinterpret_cast<f32x4*>(Xs + r * kLdQK + col) = kv;
         }
-        float s = acc / scale_div;
-        if (p.encmask && p.encmask[(size_t)b * N + j]) s = -INFINITY;
-        sc[i * N + j] = s;
+        __syncthreads();
+        for (int idx = tid; idx < W * nc; idx += 256) {
+            const int i = idx / nc, j = idx - i * nc;
+            const f32x4* kr = reinterpret_cast<const f32x4*>(Xs + j * kLdQK);
+            const f32x4* qr = reinterpret_cast<const f32x4*>(qs + i * 64);
+            float acc = 0.f;
+            for (int c = 0; c < k4n; ++c) {
+                const f32x4 a = qr[c], kk = kr[c];
+                acc += (a[0] * kk[0] + a[1] * kk[1]) + (a[2] * kk[2] + a[3] * kk[3]);
+            }
+            float s = acc / scale_div;
+            if (p.encmask && p.encmask[(size_t)b * N + k0 + j]) s = -INFINITY;
+            sc[i * N + k0 + j] = s;
+        }
+        __syncthreads();
     }
-    __syncthreads();
     for (int i = wave; i < W; i += 4) {
         float mx = -INFINITY;
         for (int j = lane; j < N; j += 64) mx = fmaxf(mx, sc[i * N + j]);
@@ -899,21 +1210,50 @@ __global__ __launch_bounds__(256) void decode_cross_attention_lds_kernel(DecodeC
         sum = wave_sum(sum);
         for (int j = lane; j < N; j += 64) sc[i * N + j] = sc[i * N + j] / sum;
     }
-    __syncthreads();
+    // out[i][d] = sum_j P[i][j] V[j][d], j ascending; W * d_v <= 512 outputs: at most two per thread
+    const int nout = W * p.dv;
+    float acc[2] = {0.f, 0.f};
+    for (int k0 = 0; k0 < N; k0 += kCrossChunk) {
+        const int nc = min(kCrossChunk, N - k0);
+        __syncthreads();                                   // the probabilities are complete / the previous chunk is consumed
+        for (int r = r0; r < nc; r += 16) {
+            f32x4 vv = {0.f, 0.f, 0.f, 0.f};
+            if (col < p.dv) vv = *reinterpret_cast<const f32x4*>(vg + (size_t)(k0 + r) * p.ldkv + hd * p.dv + col);
+            *reinterpret_cast<f32x4*>(Xs + r * kLdQK + col) = vv;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int idx = tid + 256 * u;
+            if (idx < nout) {
+                const int i = idx / p.dv, d = idx - i * p.dv;
+                for (int j = 0; j < nc; ++j) acc[u] += sc[i * N + k0 + j] * Xs[j * kLdQK + d];
+            }
+        }
+    }
     float* og = p.out + (size_t)lvl * p.out_level_stride;
-    for (int idx = tid; idx < W * p.dv; idx += 256) {
-        const int i = idx / p.dv, d = idx - i * p.dv;
-        float acc = 0.f;
-        for (int j = 0; j < N; ++j) acc += sc[i * N + j] * Vs[j * kLdQK + d];
-        og[(size_t)(b * W + i) * p.ldo + hd * p.dv + d] = acc;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int idx = tid + 256 * u;
+        if (idx < nout) {
+            const int i = idx / p.dv, d = idx - i * p.dv;
+            og[(size_t)(b * W + i) * p.ldo + hd * p.dv + d] = acc[u];
+        }
     }
 }
 
 int ovc_decode_cross_attention(const DecodeCrossArgs& p, int B, int h, int levels, hipStream_t stream) {
-    if (p.n <= 0 || p.n > 128 || p.width <= 0 || p.width > OVC_MAX_BEAM) return OVC_EINVAL;
+    if (p.n <= 0 || p.n > OVC_MAX_REGIONS || p.width <= 0 || p.width > OVC_MAX_BEAM) return OVC_EINVAL;
     if (p.dk > 64 || p.dv > 64 || (p.dk & 3) || (p.dv & 3) || p.heads != h) return OVC_EINVAL;
     if (p.dk == 16 || p.dk == 32 || p.dk == 64) {
         const dim3 grid(B, (h + 3) / 4, levels), block(256);
+        if (p.n > 128) {        // more regions than the register-resident instances hold: key chunks + online softmax
+            if (p.dk == 64) hipLaunchKernelGGL(decode_cross_attention_tiled_kernel<4>, grid, block, 0, stream, p);
+            else if (p.dk == 32) hipLaunchKernelGGL(decode_cross_attention_tiled_kernel<2>, grid, block, 0, stream, p);
+            else hipLaunchKernelGGL(decode_cross_attention_tiled_kernel<1>, grid, block, 0, stream, p);
+            OVC_RETURN_IF_LAUNCH_FAILED();
+            return OVC_OK;
+        }
         const bool small = p.n <= 64;
 #define OVC_CROSS(NT, SB) hipLaunchKernelGGL((decode_cross_attention_mfma_kernel<NT, SB>), grid, block, 0, stream, p)
         if (p.dk == 64) { if (small) OVC_CROSS(4, 4); else OVC_CROSS(8, 4); }
@@ -923,7 +1263,7 @@ int ovc_decode_cross_attention(const DecodeCrossArgs& p, int B, int h, int level
         OVC_RETURN_IF_LAUNCH_FAILED();
         return OVC_OK;
     }
-    const size_t lds_bytes = sizeof(float) * (2 * (size_t)p.n * kLdQK + (size_t)p.width * 64 + (size_t)p.width * p.n);
+    const size_t lds_bytes = sizeof(float) * ((size_t)kCrossChunk * kLdQK + (size_t)p.width * 64 + (size_t)p.width * p.n);
     static std::once_flag attr_once;
     std::call_once(attr_once, [] {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(decode_cross_attention_lds_kernel),

@@ -631,14 +631,14 @@ extern "C" const char* ovc_build_info(void) {
 }
 
 extern "C" size_t ovc_workspace_bytes(const ovc_model* m, int B, int N, int k, int return_probs) {
-    if (!model_ok(m) || B <= 0 || N <= 0 || N > 128 || k <= 0 || k > OVC_MAX_BEAM) return 0;
+    if (!model_ok(m) || B <= 0 || N <= 0 || N > OVC_MAX_REGIONS || k <= 0 || k > OVC_MAX_BEAM) return 0;
     return carve(m, nullptr, B, N, k, return_probs).bytes;
 }
 
 // Every distinct GEMM the engine issues for (B, N, k), found by running the launch sequence itself in dry mode (no
 // launch, no device access: the workspace is carved at a fake base address that is never dereferenced).
 extern "C" int ovc_engine_gemm_shapes(const ovc_model* m, int B, int N, int k, int32_t* shapes, int capacity) {
-    if (!model_ok(m) || B <= 0 || N <= 0 || N > 128 || k <= 0 || k > OVC_MAX_BEAM || capacity < 0 || (capacity > 0 && !shapes)) return OVC_EINVAL;
+    if (!model_ok(m) || B <= 0 || N <= 0 || N > OVC_MAX_REGIONS || k <= 0 || k > OVC_MAX_BEAM || capacity < 0 || (capacity > 0 && !shapes)) return OVC_EINVAL;
     Workspace w = carve(m, reinterpret_cast<void*>(uintptr_t(1) << 20), B, N, k, 0);
     std::vector<GemmShape> found;
     Engine e{m, nullptr, 0};
@@ -654,7 +654,7 @@ extern "C" int ovc_engine_gemm_shapes(const ovc_model* m, int B, int N, int k, i
 extern "C" int ovc_encode(const ovc_model* m, const float* features, const float* boxes, int B, int N,
                           void* workspace, size_t workspace_bytes, float* enc_out, uint8_t* mask_out,
                           ovc_stream stream) {
-    if (!model_ok(m) || !features || !workspace || !enc_out || !mask_out || B <= 0 || N <= 0 || N > 128) return OVC_EINVAL;
+    if (!model_ok(m) || !features || !workspace || !enc_out || !mask_out || B <= 0 || N <= 0 || N > OVC_MAX_REGIONS) return OVC_EINVAL;
     TRY(ovc_device_guard());
     if (!ovc_aligned16(features) || !ovc_aligned16(workspace) || !ovc_aligned16(enc_out)) return OVC_EINVAL;
     Workspace w = carve(m, workspace, B, N, 1, 0);
@@ -678,7 +678,7 @@ extern "C" int ovc_beam_search(const ovc_model* m, const float* features, const 
                                float* logp_out, float* all_logp_out, ovc_stream stream) {
     if (!model_ok(m) || !features || !workspace || !ids_out || !logp_out) return OVC_EINVAL;
     TRY(ovc_device_guard());
-    if (B <= 0 || N <= 0 || N > 128 || k <= 0 || k > OVC_MAX_BEAM || out_size <= 0 || out_size > k) return OVC_EINVAL;
+    if (B <= 0 || N <= 0 || N > OVC_MAX_REGIONS || k <= 0 || k > OVC_MAX_BEAM || out_size <= 0 || out_size > k) return OVC_EINVAL;
     if ((long)m->vocab < k) return OVC_EINVAL;
     if (!ovc_aligned16(features) || !ovc_aligned16(workspace)) return OVC_EINVAL;
     const int return_probs = all_logp_out != nullptr;
@@ -775,7 +775,7 @@ extern "C" int ovc_beam_search_graph(const ovc_model* m, const float* features, 
                                      float* logp_out, ovc_stream stream) {
     if (!model_ok(m) || !features || !workspace || !ids_out || !logp_out) return OVC_EINVAL;
     TRY(ovc_device_guard());
-    if (B <= 0 || N <= 0 || N > 128 || k <= 0 || k > OVC_MAX_BEAM || out_size <= 0 || out_size > k) return OVC_EINVAL;
+    if (B <= 0 || N <= 0 || N > OVC_MAX_REGIONS || k <= 0 || k > OVC_MAX_BEAM || out_size <= 0 || out_size > k) return OVC_EINVAL;
     if ((long)m->vocab < k) return OVC_EINVAL;
     if (!ovc_aligned16(features) || !ovc_aligned16(workspace)) return OVC_EINVAL;
     Workspace w = carve(m, workspace, B, N, k, 0);

@@ -314,12 +314,22 @@ class CaptionEngine:
         """Pad the region axis up to a multiple of ``region_bucket`` with all-zero rows.  Exact: a zero feature row IS
         the reference's padding (``utils/instance.py:156-171`` pads ragged batches the same way, ``models/utils.py:48-61``
         masks such rows as keys, positions are indexed by region), and every GEMM sums K in a shape-independent order.
+        (Encoders with memory slots: the slots follow the regions in the key order, so padding moves them to other
+        accumulator registers -- the same math in another summation order, equal up to rounding, not bit for bit.)
         Fewer distinct N means fewer captured graphs when the region count varies from batch to batch."""
         bucket = max(1, int(self.region_bucket))
         N = features.shape[1]
         target = -(-N // bucket) * bucket
-        if target > 128:            # the bucket would pass the kernels' region limit: keep the exact shape (N > 128 then
-            target = N              # reaches ovc_workspace_bytes and raises -- padding is never allowed to crop)
+        if target > native.OVC_MAX_REGIONS:   # the bucket would pass the engine's region limit: keep the exact shape (an N beyond
+            target = N                        # the limit then reaches ovc_workspace_bytes and raises -- padding never crops)
+        # Up to 128 keys (regions + the encoder's memory slots) the attention kernels keep a query's scores in registers, beyond
+        # that the keys pass in tiles under an online softmax (csrc/attention.hip): the two forms round differently, so a
+        # bucket never carries a batch across that edge -- the padded decode stays bit-identical to the unpadded one.
+        memory = int(getattr(getattr(self, "desc", None), "memory", 0) or 0)
+        for edge in sorted({max(128 - memory, 0), 128}):
+            if N <= edge < target:
+                target = edge
+                break
         if target == N:
             return features, boxes
         pad = target - N

@@ -11,6 +11,7 @@ from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_int64
 OVC_MAX_LAYERS = 8
 OVC_MAX_LEVELS = 4
 OVC_MAX_BEAM = 8
+OVC_MAX_REGIONS = 1024
 OVC_PROFILE_CLASSES = 4
 ABI_VERSION = 6
 

