@@ -83,6 +83,9 @@ def parse():
                     help="with --precision f32 on one GPU: an extra, separately reported leg in this opt-in mode "
                          "(same streams, same steps; never part of `value`)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--allow-measurement-hooks", action="store_true",
+                    help="tools/ only: run although OVC_DEBUG_* / OVC_KSPLIT_* / a kernel A/B switch is set or the measurement build of "
+                         "the library (tools/libovc_hooks.so) is loaded.  The line then says \"valid_for_credit\": false.")
     ap.add_argument("--cpu-sample", type=int, default=256, help="images per CPU-oracle repeat (BASELINE.md: B=256; ~12 s each on 16 cores)")
     ap.add_argument("--cpu-repeats", type=int, default=3)
     return ap.parse_args()
@@ -142,6 +145,27 @@ def algorithmic_bytes(variant, B):
     cross-attention K/V written once, 240 B of ids and log-probs out; the weights once per batch."""
     weights = WEIGHT_BYTES.get(variant)
     return None if weights is None else float(B * (409600 + 614400 + 240) + weights)
+
+
+# Switches that change result bits, skip work or select another kernel.  The shipped library does not read them at all
+# (csrc/common.h: they exist only in the -DOVC_MEASUREMENT_HOOKS build of tools/); a benchmark line produced with one of
+# them set, or with that build loaded, is not a measurement of the product.
+HOOK_PREFIXES = ("OVC_DEBUG_", "OVC_KSPLIT_")
+HOOK_SWITCHES = ("OVC_SELECT_TWO_PASS", "OVC_VOCAB_ROW_MAJOR", "OVC_K1_SEPARATE", "OVC_SELF_ATTENTION_ROWS", "OVC_ATTENTION_GENERAL")
+RECORDED_PREFIXES = ("OVC_", "GPU_MAX_HW_QUEUES", "HIP_FORCE_DEV_KERNARG", "HSA_", "ROCR_", "HIP_VISIBLE", "CUDA_VISIBLE", "NCCL_", "RCCL_")
+
+
+def measurement_hooks_in(environ, build_info=""):
+    """Names of the measurement hooks active for this process: environment switches and the hooks build itself."""
+    found = sorted(k for k in environ if k.startswith(HOOK_PREFIXES) or k in HOOK_SWITCHES)
+    if "measurement-hooks" in build_info:
+        found.append("library built with -DOVC_MEASUREMENT_HOOKS")
+    return found
+
+
+def recorded_environment(environ):
+    """What the line says it ran with: every OVC_* / HIP-runtime variable that can influence speed or the engine's mode."""
+    return {k: environ[k] for k in sorted(environ) if k.startswith(RECORDED_PREFIXES)}
 
 
 def usable_cores():
@@ -233,6 +257,13 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device; the engine has no CPU path")
+    from openviic_amd import native as _native
+    build_info = _native.load().ovc_build_info().decode()
+    hooks = measurement_hooks_in(os.environ, build_info)
+    if hooks and not args.allow_measurement_hooks:
+        raise SystemExit("bench.py: measurement hooks are active (%s): results would not be the product's.  Unset them / load the "
+                         "default library, or pass --allow-measurement-hooks (tools/ only; the line is then marked invalid for credit)."
+                         % ", ".join(hooks))
     # one rank per GPU; if the launcher narrows each rank's visible devices to its own GPU, LOCAL_RANK still counts up
     device_index = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(device_index)
@@ -405,23 +436,22 @@ def main():
         if tot_ms > single_ms * 1.02:
             print("[bench] WARNING: GEMM kernel time %.3f ms exceeds the single-stream step %.3f ms (profiler attached?)"
                   % (tot_ms, single_ms), file=sys.stderr, flush=True)
-        # K1: the padding-mask kernel is the path's one HBM-bound pass over the
-        # features (B*N*d_feat fp32 in, B*N bytes out); torch events on the stream it is launched on.
-        from openviic_amd import ops
-        k1_feats = feats[:B]
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        for _ in range(3):
-            ops.zero_row_mask(k1_feats)
-        ev0.record()
-        for _ in range(20):
-            ops.zero_row_mask(k1_feats)
-        ev1.record()
-        torch.cuda.synchronize()
-        k1_us = ev0.elapsed_time(ev1) / 20 * 1e3
-        k1_bytes = k1_feats.numel() * 4 + k1_feats.shape[0] * k1_feats.shape[1]
-        roofline["k1_hbm"] = {"kernel": "zero_row_mask_kernel", "bound": "hbm", "bytes_per_launch": k1_bytes,
-                              "avg_us": round(k1_us, 2), "achieved": round(k1_bytes / k1_us / 1e3, 1), "peak": 8000.0,
-                              "unit": "GB/s", "frac": round(k1_bytes / k1_us / 1e3 / 8000.0, 4)}
+        # K1: the path's one pass over the caller's features.  Since round 3 the padding mask is found by the
+        # feature projection itself while it stages its A tiles (GemmArgs::zero_rows_out), so the pass IS that GEMM launch: its
+        # algorithmic bytes (features in, weight in, projected rows + mask out) over its kernel-scoped duration from the same
+        # instrumented batch as above.  (Rounds 1-3 timed the stand-alone mask kernel here, 23 times over a tensor that fits the
+        # Infinity Cache -- a kernel the fp32 engine no longer launches.)  The launch is matrix-bound, not HBM-bound: both shown.
+        fp = per_class.get("feature_proj")
+        if fp:
+            d_model = int(cfg.VISION_EMBEDDING.D_MODEL)
+            fp_bytes = 4.0 * (B * N_REGIONS * D_FEAT + d_model * D_FEAT + B * N_REGIONS * d_model) + B * N_REGIONS
+            fp_us = 1e3 * fp["ms"] / fp["launches"]
+            roofline["k1_feature_pass"] = {
+                "kernel": "the feature projection GEMM (gemm_f32_mfma, M = B*N, K = d_feat) incl. the padding mask it finds while staging A",
+                "bound": "mfma", "bytes_per_launch": fp_bytes, "avg_us": round(fp_us, 2),
+                "achieved": fp["tflops"], "peak": PEAK, "unit": "TFLOP/s", "frac": round(fp["tflops"] / PEAK, 4),
+                "hbm": {"achieved": round(fp_bytes / fp_us / 1e3, 1), "peak": 8000.0, "unit": "GB/s",
+                        "frac": round(fp_bytes / fp_us / 1e3 / 8000.0, 4)}}
         if gflop:
             e2e = captions_per_s / world * gflop / 1e3
             roofline["end_to_end"] = {"gflop_per_caption": gflop, "achieved": round(e2e, 2),
@@ -473,13 +503,21 @@ def main():
             "config": {"workload": "%s beam=%d, B=%d per GPU, %dx%d synthetic regions, V=%d, max_len=%d, "
                                    "random-init weights" % (variant, k, B, N_REGIONS, D_FEAT, V, T),
                        "global_batch": B * world, "parallelism": "dp%d" % world, "streams": len(streams),
-                       "gemm_tuning_objective": {"timed_region": objective, "single_stream_leg": 1}},
+                       "gemm_tuning_objective": {"timed_region": objective, "single_stream_leg": 1},
+                       "library": build_info, "environment": recorded_environment(os.environ)},
             "roofline": roofline,
         }
+        if hooks:
+            result["measurement_hooks"] = hooks
+            result["valid_for_credit"] = False
         if also:
             result["opt_in_precision"] = also
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(cfg, sd, variant, k, args.cpu_sample, args.cpu_repeats)
+        elif world > 1:
+            # the bench contract times the CPU path on rank 0 at N = 1 only; the N > 1 lines point there instead of dropping the key
+            result["cpu_baseline"] = {"value": None, "unit": "captions/s", "kind": "port",
+                                      "sample": "not timed at N > 1: see the N = 1 line of the same run (bench contract: rank 0, N = 1 only)"}
         sys.stdout.flush()
         os.dup2(stdout_fd, 1)
         print(json.dumps(result), flush=True)

@@ -277,7 +277,8 @@ const char* ovc_profile_kernel_name(int tiling);   /* "" past the last tiling */
  *
  * ovc_gemm_tune measures every tiling OF THE GIVEN CLASS on the shape y[M, nseg*seg_n] = x[M,K] W^T (nseg weight
  * segments of seg_n rows; ksplit > 1 needs nseg == 1) and remembers the fastest for this process; later GEMMs of
- * that shape and class use it, and shapes whose M is within a factor of two of a measured one borrow its entry.
+ * that shape and class use it, and shapes whose M is within a factor of two of a measured one (or, single-segment products with
+ * the same M, whose seg_n is) borrow its entry.
  * scratch: >= 4*(M*K + nseg*seg_n*K + ksplit*M*nseg*seg_n) + 64 bytes of device memory (contents are used as
  * operands); for the split-precision classes, nseg * ovc_split_weight_bytes(seg_n, K, kchains - 100) more bytes make the
  * measurement use pre-cut weight planes (what the engine runs when ovc_lin::planes are set).  `epilogue`: 0 = the plain
@@ -296,8 +297,8 @@ int ovc_gemm_tune(int M, int seg_n, int nseg, int K, int kchains, int ksplit, in
 long ovc_gemm_tune_calls(void);        /* measurements run so far in this process */
 
 /* Read / preset the remembered tiling of (shape, class, objective): lets a host persist tuning results.  get returns
- * the tiling index or -1; near != 0 also accepts the entry of the same product with the closest M within a factor of
- * two (what a launch falls back to).  set refuses a tiling of another class. */
+ * the tiling index or -1; near != 0 also accepts the entry of the same product with the closest M -- or, M equal and nseg == 1,
+ * the closest seg_n -- within a factor of two (what a launch falls back to).  set refuses a tiling of another class. */
 int ovc_gemm_tuned_get(int M, int seg_n, int nseg, int K, int kchains, int ksplit, int objective, int near);
 int ovc_gemm_tuned_set(int M, int seg_n, int nseg, int K, int kchains, int ksplit, int objective, int tiling);
 
@@ -323,12 +324,14 @@ int ovc_debug_linear_tiling(const float* x, int K, const float* W, const float* 
 
 /* Test hook: ONE selection step of the engine's fused path on caller-supplied decoder outputs x [B*width, d] -- the
  * vocabulary product fc [V, d] with its log-softmax epilogue (transposed != 0: logits^T = fc . x^T as the fp32 engine runs
- * it; 0: the row-major form) and the fused select + update kernel, which never reads the logits back -- against which a
+ * it; 0: the row-major form; kchains = 1 or 4: the fp32 K-order class of the product -- the engine runs the transposed form
+ * with one chain -- and ovc_debug_force_gemm_tiling can pin one tiling of that class) and the fused select + update kernel,
+ * which never reads the logits back -- against which a
  * stable sort can be checked at the operator level.  chosen [B, k] = flat indices beam * V + word in winning order,
  * score [B, k]; scratch >= ovc_debug_vocab_select_bytes(B, width, V, k), 16-byte aligned.  V <= 16384. */
 size_t ovc_debug_vocab_select_bytes(int B, int width, int V, int k);
 int ovc_debug_vocab_select(const float* x, const float* fc, const float* running, const float* alive, int B, int width,
-                           int V, int d, int k, int transposed, void* scratch, size_t scratch_bytes, int64_t* chosen,
+                           int V, int d, int k, int transposed, int kchains, void* scratch, size_t scratch_bytes, int64_t* chosen,
                            float* score, ovc_stream stream);
 
 /* Split-precision modes: a weight W [N, K] (K a multiple of 16) cut ONCE into the 16-bit planes of `mode` (3 or 4, as

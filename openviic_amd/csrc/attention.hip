@@ -532,7 +532,7 @@ extern "C" int ovc_attention(const float* q, const float* k, const float* v, int
     // the accumulators.  Head sizes up to 64, key tiles up to 4 x 32: everything the path uses.
     {
         const int nkt = (nk + m + 31) / 32, waves = (nq + 31) / 32, hmax = dk > dv ? dk : dv;
-        if (nkt <= 4 && waves <= 4 && !getenv("OVC_ATTENTION_GENERAL")) {
+        if (nkt <= 4 && waves <= 4 && !OVC_HOOK_ENV("OVC_ATTENTION_GENERAL")) {
             const int k_rows = nkt * 32 > waves * 32 ? nkt * 32 : waves * 32;
             const size_t bytes = sizeof(float) * (size_t)(k_rows + nkt * 32) * kLdQK;
             const dim3 grid(b * h), block(256);
@@ -877,7 +877,7 @@ int ovc_decode_self_attention(const DecodeSelfArgs& p, int rows, hipStream_t str
     if (p.dk != p.dv || (p.dk & (p.dk - 1)) || p.dk < 4 || p.dk > 64) return OVC_EINVAL;   // dk in {4,8,16,32,64}
     if (hk > 1024) return OVC_EINVAL;
     // per-image kernel with ancestor de-duplication: the image's rows in one workgroup, at most 112 listed keys
-    static const bool per_row = getenv("OVC_SELF_ATTENTION_ROWS") != nullptr;     // A/B switch: the round-1 per-row kernel
+    static const bool per_row = OVC_HOOK_ENV("OVC_SELF_ATTENTION_ROWS") != nullptr;     // A/B switch: the round-1 per-row kernel
     const int W = p.width;
     if (!per_row && W >= 1 && W <= OVC_MAX_BEAM && rows % W == 0 && p.dk >= 16 && (p.t == 0 ? 1 : W * (p.t + 1)) <= 112) {
         const int worst = p.t == 0 ? 1 : W * (p.t + 1), tiles = (worst + 15) / 16;

@@ -413,7 +413,7 @@ __global__ __launch_bounds__(256) void beam_update_kernel(BeamUpdateArgs p) {
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Selection WITHOUT reading the logits back (round 3).  The vocabulary GEMM's epilogue leaves, per beam row and 32-column
-// block, the block's maximum and sum exp(x - maximum) (GemmArgs::stats, block-major [nblk][rows]).  One workgroup per image:
+// block, the block's maximum and sum exp(x - maximum) (GemmArgs::stats / stats_t: [rows][stats_ld] float2, row-major).  One workgroup per image:
 //   A  the row's log-softmax pieces from its nblk pairs: M = max of the block maxima, S = sum_b s_b exp(m_b - M) in a fixed
 //      order, ls = log S -- the same M the full pass finds, ls to rounding;
 //   B  every block's maximum IS a candidate: u_b = run + ((m_b - M) - ls) is the score of the block's best word, computed
@@ -771,6 +771,7 @@ extern "C" int ovc_beam_select(const float* logp, const float* running, const fl
     if (!logp || !running || !chosen || !score || B <= 0 || width <= 0 || k <= 0) return OVC_EINVAL;
     const size_t rows_k = (size_t)B * width * k;
     if (!scratch || !ovc_aligned16(scratch) || scratch_bytes < 8 * rows_k) return OVC_EWORKSPACE;
+    if (const int rc = ovc_device_guard()) return rc;          // one device per process (include/ovc.h)
     BeamSelectArgs p{};
     p.cand_v = reinterpret_cast<float*>(scratch);
     p.cand_i = reinterpret_cast<int*>(scratch) + rows_k;

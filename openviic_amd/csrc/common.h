@@ -23,6 +23,19 @@ int ovc_device_guard();
 
 static inline bool ovc_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
+// Run-time switches.  The shipped library reads no environment variable that can change a result bit, skip work or select
+// another kernel: the measurement hooks (OVC_DEBUG_*, OVC_KSPLIT_*: some of them produce garbage by design -- timing only) and
+// the A/B switches between alternative kernels exist only in a build with -DOVC_MEASUREMENT_HOOKS
+// (`python -m openviic_amd.csrc.build --hooks` -> tools/libovc_hooks.so, loaded with OVC_LIBRARY=...; ovc_build_info() says
+// so and bench.py refuses such a library for a credited line).  In the default build the names below do not even exist as
+// strings.  The one variable the default build reads is OVC_GRAPH_CACHE_MAX (the LRU bound of the hipGraph cache).
+#ifdef OVC_MEASUREMENT_HOOKS
+#include <cstdlib>
+#define OVC_HOOK_ENV(name) getenv(name)
+#else
+#define OVC_HOOK_ENV(name) (static_cast<const char*>(nullptr))
+#endif
+
 // ---- wave-level reductions (64 lanes) ------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -209,7 +209,7 @@ __global__ __launch_bounds__(256) void decode_embed_kernel(const int32_t* __rest
 // batches in flight (results are garbage; timing only).  1 = AddNorm LayerNorms, 2 = self-attention, 4 = cross-attention,
 // 8 = the vocabulary projection's selection / update.  Never set in production.
 int debug_skip() {
-    static const int mask = [] { const char* e = getenv("OVC_DEBUG_SKIP"); return e ? atoi(e) : 0; }();
+    static const int mask = [] { const char* e = OVC_HOOK_ENV("OVC_DEBUG_SKIP"); return e ? atoi(e) : 0; }();
     return mask;
 }
 
@@ -217,7 +217,7 @@ int debug_skip() {
 // does a kernel BOUNDARY cost the whole chip when several streams are in flight?  Never set in production.
 __global__ void noop_kernel() {}
 int extra_launches() {
-    static const int n = [] { const char* e = getenv("OVC_DEBUG_EXTRA_LAUNCHES"); return e ? atoi(e) : 0; }();
+    static const int n = [] { const char* e = OVC_HOOK_ENV("OVC_DEBUG_EXTRA_LAUNCHES"); return e ? atoi(e) : 0; }();
     return n;
 }
 
@@ -245,8 +245,8 @@ __global__ void interleave_levels_kernel(const float* __restrict__ levels, float
 // 4 from there on (measured on 1280 x 512 x {512, 2048}: 12.3 -> 11.1 us and 37.3 -> 27.2 us).  OVC_KSPLIT_SMALL /
 // OVC_KSPLIT_LARGE override the two values for A/B measurements (they change the summation order, hence low-order bits).
 int decode_ksplit(int K) {
-    static const int small = [] { const char* e = getenv("OVC_KSPLIT_SMALL"); return e ? atoi(e) : 2; }();
-    static const int large = [] { const char* e = getenv("OVC_KSPLIT_LARGE"); return e ? atoi(e) : 4; }();
+    static const int small = [] { const char* e = OVC_HOOK_ENV("OVC_KSPLIT_SMALL"); return e ? atoi(e) : 2; }();
+    static const int large = [] { const char* e = OVC_HOOK_ENV("OVC_KSPLIT_LARGE"); return e ? atoi(e) : 4; }();
     int s = K >= 1024 ? large : small;
     if (s != 1 && s != 2 && s != 4) s = 1;
     while (s > 1 && K % (s * 32)) s >>= 1;          // a slice is a whole number of 32-deep K tiles
@@ -379,7 +379,7 @@ int run_encoder_inputs(Engine& e, Workspace& w, const float* features, const flo
         GemmArgs a{};
         a.A1 = features; a.lda1 = m->d_feat; a.K1 = m->d_feat; a.M = BN; a.seg_n = d; a.nseg = 1; a.ldc = d;
         a.seg[0] = e.seg(m->proj, w.ey);
-        static const bool separate = getenv("OVC_K1_SEPARATE") != nullptr;        // A/B switch: the round-1 mask kernel
+        static const bool separate = OVC_HOOK_ENV("OVC_K1_SEPARATE") != nullptr;        // A/B switch: the round-1 mask kernel
         if (m->precision == 0 && !separate) a.zero_rows_out = w.enc_mask;
         else RUN(ovc_zero_row_mask(features, BN, m->d_feat, w.enc_mask, s));
         TRY(e.gemm(a));
@@ -471,7 +471,7 @@ int run_decode_step(Engine& e, Workspace& w, int B, int N, int k, int t, int ret
     e.gemm_class = 2;
     e.kchains = 4;            // M = B*width products: four chains, so that 32x32 / 32x64 tiles can spread them over waves
     {   // measurement hook: another K-order class for the decode-step products (changes low-order bits; never set in production)
-        static const int forced = [] { const char* v = getenv("OVC_DEBUG_DECODE_KCHAINS"); return v ? atoi(v) : 0; }();
+        static const int forced = [] { const char* v = OVC_HOOK_ENV("OVC_DEBUG_DECODE_KCHAINS"); return v ? atoi(v) : 0; }();
         if (forced == 1 || forced == 4) e.kchains = forced;
     }
     float* x = w.x;
@@ -557,7 +557,7 @@ int run_decode_step(Engine& e, Workspace& w, int B, int N, int k, int t, int ret
     // and ONE kernel per image selects and updates from those pieces.  Vocabularies beyond 16 384 words (more than 512 blocks)
     // and OVC_SELECT_TWO_PASS (A/B switch) take the round-2 pair of kernels that read every logit back.
     const int nblk = (m->vocab + 31) / 32;
-    static const bool two_pass = getenv("OVC_SELECT_TWO_PASS") != nullptr;
+    static const bool two_pass = OVC_HOOK_ENV("OVC_SELECT_TWO_PASS") != nullptr;
     const bool fused_select = !two_pass && nblk <= 512;
     // fp32 mode + fused selection: the product runs TRANSPOSED -- logits^T [V][rows] = fc [V, d] . x^T, the same kernel with the
     // operands' roles swapped (both are K-contiguous) and the same bits (every dot product sums the same k order; a * b
@@ -565,7 +565,7 @@ int run_decode_step(Engine& e, Workspace& w, int B, int N, int k, int t, int ret
     // in-register reduction (~70 vector instructions per tile instead of ~370 across lanes), and a store instruction still
     // writes whole 128-byte lines (32 consecutive beam rows of one word).  The split-precision modes keep the row-major
     // product: their pre-cut weight planes are B-operand planes.
-    static const bool row_major = getenv("OVC_VOCAB_ROW_MAJOR") != nullptr;        // A/B switch
+    static const bool row_major = OVC_HOOK_ENV("OVC_VOCAB_ROW_MAJOR") != nullptr;        // A/B switch
     const bool transposed = fused_select && m->precision == 0 && !row_major;
     const int ldt = (rows + 3) & ~3;               // row stride of logits^T
     {
@@ -574,7 +574,7 @@ int run_decode_step(Engine& e, Workspace& w, int B, int N, int k, int t, int ret
         // the accumulator registers: +1.2 % captions/s with four batches in flight, +0.5 % on one stream, same-box A/B).  The
         // row-major form of the split-precision modes keeps its class.  OVC_DEBUG_VOCAB_KCHAINS=4: A/B switch (changes the
         // logits' low-order bits).
-        static const int vocab_chains = [] { const char* v = getenv("OVC_DEBUG_VOCAB_KCHAINS"); return v ? atoi(v) : 0; }();
+        static const int vocab_chains = [] { const char* v = OVC_HOOK_ENV("OVC_DEBUG_VOCAB_KCHAINS"); return v ? atoi(v) : 0; }();
         const int saved_chains = e.kchains;
         if (transposed) e.kchains = vocab_chains == 4 ? 4 : 1;
         GemmArgs g{};
@@ -627,7 +627,12 @@ int run_decode_step(Engine& e, Workspace& w, int B, int N, int k, int t, int ret
 extern "C" int ovc_abi_version(void) { return 6; }
 
 extern "C" const char* ovc_build_info(void) {
+#ifdef OVC_MEASUREMENT_HOOKS
+    // a tools/ build: OVC_DEBUG_* / OVC_KSPLIT_* / the A/B switches are read from the environment -- never for results or a credited number
+    return "libovc gfx950 (CDNA4) fp32: v_mfma_f32_32x32x2_f32 GEMM + attention, HIP " __DATE__ " +measurement-hooks";
+#else
     return "libovc gfx950 (CDNA4) fp32: v_mfma_f32_32x32x2_f32 GEMM + attention, HIP " __DATE__;
+#endif
 }
 
 extern "C" size_t ovc_workspace_bytes(const ovc_model* m, int B, int N, int k, int return_probs) {
@@ -831,8 +836,9 @@ extern "C" int ovc_beam_search_graph(const ovc_model* m, const float* features, 
 }
 
 // Test hook: ONE selection step of the fused path on caller-supplied decoder outputs -- the vocabulary product with its
-// log-softmax epilogue (transposed != 0: the fp32 engine's form, logits^T = fc . x^T; 0: the row-major form of the
-// split-precision modes) followed by beam_fused_update_kernel -- so that the selection can be checked against a stable sort
+// log-softmax epilogue (transposed != 0: the fp32 engine's form, logits^T = fc . x^T, which the engine runs in the one-chain
+// class, kchains = 1; 0: the row-major form of the split-precision modes; kchains = 1 / 4 picks the fp32 K-order class, and
+// with it the tiling instances whose epilogue runs -- ovc_debug_force_gemm_tiling narrows it to one) followed by beam_fused_update_kernel -- so that the selection can be checked against a stable sort
 // at the operator level (tests/test_ops_gpu.py).  x [B*width, d], fc [V, d], running / alive [B*width]; chosen [B, k] receives
 // flat indices beam * V + word in winning order, score [B, k] their scores.  scratch: ovc_debug_vocab_select_bytes.
 extern "C" size_t ovc_debug_vocab_select_bytes(int B, int width, int V, int k) {
@@ -842,10 +848,10 @@ extern "C" size_t ovc_debug_vocab_select_bytes(int B, int width, int V, int k) {
 }
 
 extern "C" int ovc_debug_vocab_select(const float* x, const float* fc, const float* running, const float* alive, int B, int width,
-                                      int V, int d, int k, int transposed, void* scratch, size_t scratch_bytes, int64_t* chosen,
-                                      float* score, ovc_stream stream) {
+                                      int V, int d, int k, int transposed, int kchains, void* scratch, size_t scratch_bytes,
+                                      int64_t* chosen, float* score, ovc_stream stream) {
     if (!x || !fc || !running || !alive || !scratch || !chosen || !score || B <= 0 || width <= 0 || width > OVC_MAX_BEAM || k <= 0 ||
-        k > OVC_MAX_BEAM || V < k || d <= 0 || (d & 3) || (V + 31) / 32 > 512) return OVC_EINVAL;
+        k > OVC_MAX_BEAM || V < k || d <= 0 || (d & 3) || (V + 31) / 32 > 512 || (kchains != 1 && kchains != 4)) return OVC_EINVAL;
     if (scratch_bytes < ovc_debug_vocab_select_bytes(B, width, V, k) || !ovc_aligned16(scratch)) return OVC_EWORKSPACE;
     TRY(ovc_device_guard());
     hipStream_t s = ovc_hip_stream(stream);
@@ -858,7 +864,7 @@ extern "C" int ovc_debug_vocab_select(const float* x, const float* fc, const flo
     int32_t* hist_out = a.take<int32_t>((size_t)B * k); int32_t* anc_out = a.take<int32_t>((size_t)B * k);
     int32_t* next_tok = a.take<int32_t>((size_t)B * k);
     GemmArgs g{};
-    g.kchains = 4; g.K1 = d; g.lda1 = d; g.nseg = 1; g.stats_ld = ld;
+    g.kchains = kchains; g.K1 = d; g.lda1 = d; g.nseg = 1; g.stats_ld = ld;     // the fp32 engine: transposed, one chain
     if (transposed) {
         g.A1 = fc; g.M = V; g.seg_n = rows; g.ldc = ldt; g.seg[0] = GemmSegment{x, nullptr, logits, nullptr, nullptr}; g.stats_t = stats;
     } else {

@@ -663,7 +663,7 @@ std::vector<TunedShape> g_tuned;
 std::mutex g_tuned_mutex;
 std::atomic<long> g_tune_calls{0};      // measurements actually run (tests assert that bucketed shapes re-use entries)
 
-// Exact entry, or (near = true) the entry of the same product whose M is closest within a factor of two: the best
+// Exact entry, or (near = true) the entry of the same product whose M (or, with M equal, whose column count) is closest within a factor of two: the best
 // tiling moves slowly with M, and every tiling of a class gives the same bits, so borrowing a neighbour's choice
 // costs at most a little speed.  Batches whose region count varies (M = B*N) then never wait for a tuning run.
 // `objective` = how many identical products co-ran when the entry was measured (ovc_gemm_tune_objective): a caller that
@@ -673,10 +673,17 @@ int tuned_lookup(int M, int seg_n, int nseg, int K, int kchains, int ksplit, int
     int best = -1;
     double best_ratio = 2.0;
     for (const TunedShape& t : g_tuned) {
-        if (t.seg_n != seg_n || t.nseg != nseg || t.K != K || t.kchains != kchains || t.ksplit != ksplit || t.objective != objective) continue;
-        if (t.M == M) return t.tiling;
+        if (t.nseg != nseg || t.K != K || t.kchains != kchains || t.ksplit != ksplit || t.objective != objective) continue;
+        if (t.M == M && t.seg_n == seg_n) return t.tiling;
         if (!near) continue;
-        const double ratio = t.M > M ? (double)t.M / M : (double)M / t.M;
+        // a neighbour along ONE axis: the same columns with M within a factor of two, or -- single-segment products -- the same
+        // rows with the column count within a factor of two.  The second form is the transposed vocabulary product's (M = V
+        // words, seg_n = B * width beam rows): the batch size moves its COLUMNS, and the ragged last batch of a prediction loop
+        // must not wait for a stream-synchronising measurement of the decode step's heaviest product.
+        double ratio;
+        if (t.seg_n == seg_n) ratio = t.M > M ? (double)t.M / M : (double)M / t.M;
+        else if (t.M == M && nseg == 1) ratio = t.seg_n > seg_n ? (double)t.seg_n / seg_n : (double)seg_n / t.seg_n;
+        else continue;
         if (ratio <= best_ratio) { best_ratio = ratio; best = t.tiling; }
     }
     return best;
@@ -958,6 +965,7 @@ extern "C" size_t ovc_split_weight_bytes(int N, int K, int mode) {
 
 extern "C" int ovc_split_weight(const float* W, int N, int K, int mode, void* planes, ovc_stream stream) {
     if (!W || !planes || !ovc_split_weight_bytes(N, K, mode) || !ovc_aligned16(planes)) return OVC_EINVAL;
+    if (const int rc = ovc_device_guard()) return rc;          // one device per process (include/ovc.h)
     const dim3 grid(K >> 4, (N + 31) / 32);
     u32x4* out = reinterpret_cast<u32x4*>(planes);
     if (mode == 3) hipLaunchKernelGGL(split_weight_kernel<3>, grid, dim3(64), 0, ovc_hip_stream(stream), W, N, K, out);

@@ -276,6 +276,7 @@ extern "C" int ovc_layer_norm(const float* x, const float* residual, const float
                               float* y, int rows, int d, ovc_stream stream) {
     if (!x || !gamma || !beta || !y || rows <= 0 || d <= 0 || (d & 3) || d > 64 * 4 * kMaxVec) return OVC_EINVAL;
     if (add && add_rows <= 0) return OVC_EINVAL;
+    if (const int rc = ovc_device_guard()) return rc;          // one device per process (include/ovc.h)
     if (!ovc_aligned16(x) || !ovc_aligned16(y) || !ovc_aligned16(gamma) || !ovc_aligned16(beta) ||
         (residual && !ovc_aligned16(residual)) || (add && !ovc_aligned16(add))) return OVC_EINVAL;
     hipStream_t s = ovc_hip_stream(stream);
@@ -295,6 +296,7 @@ int ovc_layer_norm_parts(const float* parts, int nparts, long part_stride, const
 
 extern "C" int ovc_zero_row_mask(const float* x, int rows, int d, uint8_t* mask, ovc_stream stream) {
     if (!x || !mask || rows <= 0 || d <= 0 || (d & 3) || !ovc_aligned16(x)) return OVC_EINVAL;
+    if (const int rc = ovc_device_guard()) return rc;          // one device per process (include/ovc.h)
     hipLaunchKernelGGL(zero_row_mask_kernel, dim3((rows + 3) / 4), dim3(256), 0, ovc_hip_stream(stream), x, rows, d, mask);
     OVC_RETURN_IF_LAUNCH_FAILED();
     return OVC_OK;
@@ -303,6 +305,7 @@ extern "C" int ovc_zero_row_mask(const float* x, int rows, int d, uint8_t* mask,
 extern "C" int ovc_region_position_encoding(const uint8_t* mask, int b, int n, int d, float temperature,
                                             int normalize, float scale, float* pe, ovc_stream stream) {
     if (!pe || b <= 0 || n <= 0 || d <= 0) return OVC_EINVAL;
+    if (const int rc = ovc_device_guard()) return rc;          // one device per process (include/ovc.h)
     const long total = (long)b * n * d;
     hipLaunchKernelGGL(region_pe_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ovc_hip_stream(stream), mask, b, n, d,
                        temperature, normalize, scale, pe);
@@ -315,6 +318,7 @@ extern "C" int ovc_embed(const int64_t* tokens, const int64_t* positions, const 
     if (!tokens || !table || !y || rows <= 0 || d <= 0 || (d & 3) || table_rows <= 0) return OVC_EINVAL;
     if (pos_table && positions && pos_rows <= 0) return OVC_EINVAL;
     if (!ovc_aligned16(table) || !ovc_aligned16(y) || (pos_table && !ovc_aligned16(pos_table))) return OVC_EINVAL;
+    if (const int rc = ovc_device_guard()) return rc;          // one device per process (include/ovc.h)
     hipLaunchKernelGGL(embed_kernel, dim3((rows + 3) / 4), dim3(256), 0, ovc_hip_stream(stream), tokens, positions, table,
                        table_rows, pos_table, pos_rows, y, rows, d);
     OVC_RETURN_IF_LAUNCH_FAILED();
@@ -328,6 +332,7 @@ static inline int elementwise_grid(long n4) {
 
 extern "C" int ovc_sigmoid_gate(const float* a, const float* g, float* y, long n, ovc_stream stream) {
     if (!a || !g || !y || n <= 0 || (n & 3) || !ovc_aligned16(a) || !ovc_aligned16(g) || !ovc_aligned16(y)) return OVC_EINVAL;
+    if (const int rc = ovc_device_guard()) return rc;          // one device per process (include/ovc.h)
     hipLaunchKernelGGL(sigmoid_gate_kernel, dim3(elementwise_grid(n / 4)), dim3(256), 0, ovc_hip_stream(stream), a, g, y, n / 4);
     OVC_RETURN_IF_LAUNCH_FAILED();
     return OVC_OK;
@@ -337,6 +342,7 @@ extern "C" int ovc_gated_accumulate(const float* acc_in, const float* alpha, con
                                     float* acc_out, long n, ovc_stream stream) {
     if (!alpha || !x || !acc_out || n <= 0 || (n & 3)) return OVC_EINVAL;
     if (!ovc_aligned16(alpha) || !ovc_aligned16(x) || !ovc_aligned16(acc_out) || (acc_in && !ovc_aligned16(acc_in))) return OVC_EINVAL;
+    if (const int rc = ovc_device_guard()) return rc;          // one device per process (include/ovc.h)
     hipLaunchKernelGGL(gated_accumulate_kernel, dim3(elementwise_grid(n / 4)), dim3(256), 0, ovc_hip_stream(stream),
                        acc_in, alpha, x, divisor, acc_out, n / 4);
     OVC_RETURN_IF_LAUNCH_FAILED();
@@ -352,6 +358,7 @@ int ovc_meshed_mix(const float* alpha, const float* enc, int levels, long n, flo
 
 extern "C" int ovc_log_softmax(const float* x, float* y, int rows, int n, ovc_stream stream) {
     if (!x || !y || rows <= 0 || n <= 0) return OVC_EINVAL;
+    if (const int rc = ovc_device_guard()) return rc;          // one device per process (include/ovc.h)
     hipLaunchKernelGGL(log_softmax_kernel, dim3(rows), dim3(256), 0, ovc_hip_stream(stream), x, y, rows, n);
     OVC_RETURN_IF_LAUNCH_FAILED();
     return OVC_OK;
@@ -361,6 +368,7 @@ extern "C" int ovc_box_relation_weights(const float* boxes, int b, int n, const 
                                         int h, int d_g, int trig, float* w, ovc_stream stream) {
     if (!boxes || !fc_w || !fc_b || !w || b <= 0 || n <= 0 || h <= 0) return OVC_EINVAL;
     if ((!trig && d_g != 4) || (trig && (d_g <= 0 || (d_g & 7)))) return OVC_EINVAL;
+    if (const int rc = ovc_device_guard()) return rc;          // one device per process (include/ovc.h)
     hipLaunchKernelGGL(box_relation_kernel, dim3(b * n), dim3(64), 0, ovc_hip_stream(stream), boxes, n, fc_w, fc_b, h, d_g,
                        trig, w);
     OVC_RETURN_IF_LAUNCH_FAILED();

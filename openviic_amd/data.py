@@ -9,6 +9,7 @@ counts, and those zero rows are what ``FeatureEmbedding`` turns into the padding
 A pickled dict can execute code on load, so ``load_feature_file`` refuses pickles unless
 ``trusted=True`` is passed; ``.npz`` archives of plain arrays load without pickle.
 """
+import functools
 import os
 from typing import Iterable, Optional, Sequence
 
@@ -53,7 +54,8 @@ def batch_from_feature_files(paths: Sequence[str], keys: Optional[Iterable[str]]
     order of the batch is the order of ``paths`` either way."""
     keys = tuple(keys) if keys is not None else None
     if pool is not None:
-        instances = list(pool.map(lambda path: _instance_from_file(path, keys, trusted), paths))
+        # a partial of a top-level function pickles, a lambda does not: works with thread AND process pools (ADVICE r3)
+        instances = list(pool.map(functools.partial(_instance_from_file, keys=keys, trusted=trusted), paths))
     else:
         instances = [_instance_from_file(path, keys, trusted) for path in paths]
     batch = InstanceList(instances)

@@ -231,8 +231,10 @@ class CaptionEngine:
 
     def tune(self, B, N, k):
         """Time the GEMM tilings of each of the engine's (shape, K-order class) once and let the library remember the
-        fastest (synchronises; ~0.2 s).  Speed only: all tilings of a class give the same bits.  Shapes for which the
-        library already holds a MEASURED entry with M within a factor of two (another region count or batch size) borrow its
+        fastest (synchronises; every tiling of the class runs 2 + 3 x 6 launches per shape: ~0.5 s for the BASELINE model's
+        shapes).  Speed only: all tilings of a class give the same bits.  Shapes for which the
+        library already holds a MEASURED entry with M within a factor of two (another region count or batch size; for the
+        transposed vocabulary product, whose batch size is its column count: seg_n within a factor of two) borrow its
         choice and are not measured, so batches whose N varies inside such a range never wait here after the first one (a
         shape that borrowed leaves no entry of its own: a later shape beyond the factor of two of every measured M is measured
         once more)."""

@@ -105,7 +105,7 @@ SIGNATURES = {
     "ovc_debug_clear_tuning": (c_int, []),
     "ovc_debug_linear_tiling": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "ovc_debug_vocab_select_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
-    "ovc_debug_vocab_select": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p,
+    "ovc_debug_vocab_select": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p,
                                        c_size_t, c_void_p, c_void_p, c_void_p]),
     "ovc_split_weight_bytes": (c_size_t, [c_int, c_int, c_int]),
     "ovc_split_weight": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),

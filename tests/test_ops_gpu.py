@@ -165,27 +165,27 @@ def test_attention_key_tiles_that_are_entirely_masked():
     _close(got, _sdpa_ref(q, k, v, h, keymask, None, memory), what="memory slots behind masked tiles")
 
 
-def test_attention_general_kernel_still_agrees(monkeypatch):
-    """The register-resident kernel serves every shape of the path; the LDS-score kernel stays as the fallback for
-    shapes outside its instances.  Both against fp64, memory slots + key mask and geometry + per-query mask."""
+def test_attention_general_kernel_still_agrees():
+    """The register-resident kernel serves up to 128 queries x 128 keys, the key-tiled one everything beyond 128 keys; more than
+    128 queries over at most 128 keys take the LDS-score kernel (64-query tiles).  All three against fp64 on one problem
+    family: memory slots + key mask and geometry + per-query mask.  (Until round 3 an environment switch forced the LDS-score
+    kernel; the shipped library no longer reads such switches -- csrc/common.h -- so the shapes select the kernels here.)"""
     from openviic_amd import ops
     g = torch.Generator().manual_seed(12)
-    b, nq, nk, h, dk, m = 2, 50, 50, 8, 64, 40
-    q, k, v = (torch.randn(b, n, h * dk, generator=g) for n in (nq, nk, nk))
-    keymask = torch.rand(b, 1, 1, nk, generator=g) < 0.3
-    keymask[..., 0] = False
-    qmask = torch.rand(b, 1, nq, nk, generator=g) < 0.3
-    qmask[..., 0] = False
-    geometry = torch.rand(b, h, nq, nk, generator=g) * 2 - 0.5
-    memory = (torch.randn(1, m, h * dk, generator=g) / dk, torch.randn(1, m, h * dk, generator=g) / m, math.sqrt(dk), math.sqrt(m))
-    mem_dev = (memory[0].to(DEV), memory[1].to(DEV), memory[2], memory[3])
-    for general in ("", "1"):
-        if general:
-            monkeypatch.setenv("OVC_ATTENTION_GENERAL", "1")
+    for nq, nk in ((50, 50), (150, 50), (150, 120)):            # registers / LDS scores / key tiles (120 + 40 slots)
+        b, h, dk, m = 2, 8, 64, 40
+        q, k, v = (torch.randn(b, n, h * dk, generator=g) for n in (nq, nk, nk))
+        keymask = torch.rand(b, 1, 1, nk, generator=g) < 0.3
+        keymask[..., 0] = False
+        qmask = torch.rand(b, 1, nq, nk, generator=g) < 0.3
+        qmask[..., 0] = False
+        geometry = torch.rand(b, h, nq, nk, generator=g) * 2 - 0.5
+        memory = (torch.randn(1, m, h * dk, generator=g) / dk, torch.randn(1, m, h * dk, generator=g) / m, math.sqrt(dk), math.sqrt(m))
+        mem_dev = (memory[0].to(DEV), memory[1].to(DEV), memory[2], memory[3])
         got = ops.attention(q.to(DEV), k.to(DEV), v.to(DEV), h, mask=keymask.to(DEV), memory=mem_dev)
-        _close(got, _sdpa_ref(q, k, v, h, keymask, None, memory), what="memory, general=%r" % general)
+        _close(got, _sdpa_ref(q, k, v, h, keymask, None, memory), what="memory, nq=%d nk=%d" % (nq, nk))
         got = ops.attention(q.to(DEV), k.to(DEV), v.to(DEV), h, mask=qmask.to(DEV), geometry=geometry.to(DEV))
-        _close(got, _sdpa_ref(q, k, v, h, qmask, geometry), what="geometry, general=%r" % general)
+        _close(got, _sdpa_ref(q, k, v, h, qmask, geometry), what="geometry, nq=%d nk=%d" % (nq, nk))
 
 
 def test_causal_mask_attention_matches_teacher_forcing_shape():
@@ -640,15 +640,34 @@ def test_operator_wrappers_reject_mismatched_shapes():
     assert ops.linear(t(6, 32), t(16, 32), t(16)).shape == (6, 16)          # the well-formed call still works
 
 
-def _fused_select(lib, native, x, fc, running, alive, B, W, V, k, transposed):
+def _fused_select(lib, native, x, fc, running, alive, B, W, V, k, transposed, kchains=None, tiling=-1):
+    """One selection step through the fused path.  ``kchains``: the product's fp32 K-order class (default: what the engine
+    runs -- one chain for the transposed form, four for the row-major one); ``tiling`` pins one instance of that class."""
     chosen = torch.empty(B, k, dtype=torch.int64, device=DEV)
     score = torch.empty(B, k, device=DEV)
     scratch = torch.empty(lib.ovc_debug_vocab_select_bytes(B, W, V, k), dtype=torch.uint8, device=DEV)
-    rc = lib.ovc_debug_vocab_select(x.data_ptr(), fc.data_ptr(), running.data_ptr(), alive.data_ptr(), B, W, V, x.shape[1], k,
-                                    int(transposed), scratch.data_ptr(), scratch.numel(), chosen.data_ptr(), score.data_ptr(),
-                                    native.stream_handle())
+    kchains = kchains or (1 if transposed else 4)
+    assert lib.ovc_debug_force_gemm_tiling(tiling) == 0
+    try:
+        rc = lib.ovc_debug_vocab_select(x.data_ptr(), fc.data_ptr(), running.data_ptr(), alive.data_ptr(), B, W, V, x.shape[1], k,
+                                        int(transposed), kchains, scratch.data_ptr(), scratch.numel(), chosen.data_ptr(), score.data_ptr(),
+                                        native.stream_handle())
+    finally:
+        lib.ovc_debug_force_gemm_tiling(-1)
     assert rc == 0
     return chosen.cpu(), score.cpu()
+
+
+def _tilings_of_class(lib, chains):
+    out, t = [], 0
+    while lib.ovc_profile_kernel_name(t):
+        name = lib.ovc_profile_kernel_name(t).decode()
+        if name.startswith("gemm_f32_mfma<"):
+            bm, bn, wm, wn, wk, bk, nc = (int(v) for v in name[len("gemm_f32_mfma<"):-1].split(","))
+            if wk * nc == chains:
+                out.append(t)
+        t += 1
+    return out
 
 
 @pytest.mark.parametrize("B,W,V,k,d", [(6, 5, 10201, 5, 64), (9, 1, 10201, 5, 64), (3, 3, 53, 3, 32), (4, 8, 999, 8, 64),
@@ -680,10 +699,12 @@ def test_fused_selection_from_block_pieces_matches_a_stable_sort(B, W, V, k, d):
     want_val, want_idx = torch.sort(cand.view(B, -1), dim=-1, descending=True, stable=True)
     margin = (want_val[:, :k] - want_val[:, 1:k + 1]).abs()
     got = {}
-    for transposed in (1, 0):
+    # (orientation, K-order class): what the fp32 engine runs -- transposed, ONE chain (the hook used to run four) --
+    # then the four-chain transposed form and the row-major form of the split-precision modes
+    for transposed, chains in ((1, 1), (1, 4), (0, 4)):
         idx, val = _fused_select(lib, native, x.to(DEV), fc.to(DEV), running.to(DEV).contiguous(), alive.to(DEV).contiguous(), B, W, V, k,
-                                 transposed)
-        got[transposed] = (idx, val)
+                                 transposed, chains)
+        got[(transposed, chains)] = (idx, val)
         np.testing.assert_allclose(val.numpy(), want_val[:, :k].numpy(), rtol=0, atol=2e-5)
         # winners: identical wherever the next candidate is not within fp32 noise of the chosen one, or ties exactly with it
         # inside one row (then the order of the stable sort is the rule)
@@ -694,9 +715,16 @@ def test_fused_selection_from_block_pieces_matches_a_stable_sort(B, W, V, k, d):
                 if margin[b, j] > 1e-5 and (j == 0 or margin[b, j - 1] > 1e-5) or same_row_tie or prev_tie:
                     if (j == 0 or margin[b, j - 1] > 1e-5 or prev_tie) and (margin[b, j] > 1e-5 or same_row_tie):
                         assert idx[b, j] == want_idx[b, j], (b, j, idx[b], want_idx[b, :k + 1], want_val[b, :k + 1])
-    # the two orientations sum a block's exponentials in different (each fixed) orders: same winners, scores to rounding
-    assert torch.equal(got[1][0], got[0][0])
-    np.testing.assert_allclose(got[1][1].numpy(), got[0][1].numpy(), rtol=0, atol=2e-6)
+    # the orientations / classes sum a block's exponentials in different (each fixed) orders: same winners, scores to rounding
+    for other in ((1, 4), (0, 4)):
+        assert torch.equal(got[(1, 1)][0], got[other][0])
+        np.testing.assert_allclose(got[(1, 1)][1].numpy(), got[other][1].numpy(), rtol=0, atol=2e-6)
+    # every tiling of the production class (one chain: 128x128 ... 64x64, K tiles 16 / 32 / 64) leaves the same pieces:
+    # winners AND scores bit-identical whichever instance's stats_t epilogue ran
+    for tiling in _tilings_of_class(lib, 1):
+        idx, val = _fused_select(lib, native, x.to(DEV), fc.to(DEV), running.to(DEV).contiguous(), alive.to(DEV).contiguous(), B, W, V, k,
+                                 1, 1, tiling)
+        assert torch.equal(idx, got[(1, 1)][0]) and torch.equal(val, got[(1, 1)][1]), tiling
 
 
 def test_fused_selection_massive_ties_frozen_beams_and_nan_rows():
