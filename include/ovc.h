@@ -248,6 +248,23 @@ int ovc_beam_search_graph(const ovc_model* m, const float* features, const float
                           int64_t* ids_out, float* logp_out, ovc_stream stream);
 int ovc_graph_cache_clear(void);
 
+/* Same result again, WITHOUT the steps nobody needs.  The reference always runs max_len steps (models/modules/beam_search.py:94-95),
+ * although once every beam of every image has emitted <eos> a step only appends word 0 / log-prob 0 to every beam and re-orders the
+ * beams by score once -- which the final ordering does anyway (beam_search.py:49-55, 97-113).  This entry point issues the search
+ * step by step (one captured graph per step from the second call of a shape on), lets the update kernel of each step count the
+ * beams still alive, reads that count on the host ONE STEP LATE (the next step is already queued: the GPU never idles) and stops
+ * issuing steps once it reads 0; the final ordering emits word 0 / log-prob 0 for the positions never written.  ids_out / logp_out
+ * equal ovc_beam_search_graph's (assuming no total score below -999, the score of a frozen beam's other candidates,
+ * beam_search.py:54); an image without a single valid region (NaN logits, arbitrary words) counts as ended and its arbitrary
+ * words may differ.  *steps_run_out (host memory, may be NULL) receives the steps issued, 2 .. max_len.
+ * Unlike every other entry point this one BLOCKS the calling host thread (hipEventSynchronize) until the search is at most one
+ * step from its end: hosts that keep several batches in flight on different streams drive each stream from its own thread (the
+ * library is thread-safe; ctypes releases the GIL).  Pinned host memory (max_len ints) and one event per step are kept per
+ * (model, shape, workspace) next to the graphs and released with them.  No return_probs form. */
+int ovc_beam_search_early(const ovc_model* m, const float* features, const float* boxes, int B, int N,
+                          int k, int out_size, void* workspace, size_t workspace_bytes,
+                          int64_t* ids_out, float* logp_out, int* steps_run_out, ovc_stream stream);
+
 /* Optional device timing of the engine's GEMM launches (bench.py's roofline leg).  While enabled,
  * every GEMM launch carries a pair of hipEvents on its launch stream (hipExtLaunchKernelGGL start /
  * stop events, i.e. the dispatch's own begin / end timestamps, the quantity rocprofv3 reports as

@@ -93,7 +93,7 @@ class BaseTransformer(Module):
                 self._engine = engine.CaptionEngine(self)
             boxes = input_features["region_boxes"] if self.uses_boxes else None
             return self._engine.beam_search(input_features[self.feature_field], boxes, batch_size, beam_size,
-                                            out_size=out_size, return_probs=return_probs)
+                                            out_size=out_size, return_probs=return_probs, early_exit=kwargs.get("early_exit"))
         searcher = BeamSearch(model=self, max_len=self.max_len, eos_idx=self.eos_idx, beam_size=beam_size,
                               b_s=batch_size, device=self.device)
         with self.statefulness(batch_size):

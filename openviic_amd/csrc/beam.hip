@@ -406,6 +406,11 @@ __global__ __launch_bounds__(256) void beam_update_kernel(BeamUpdateArgs p) {
     if (tid < 64) {
         const Cand best = merge_row_candidates(p.cand_v, p.cand_i, b, p.width, p.k, tid);
         if (tid < p.k) beam_record_winner(p, b, tid, best.idx, best.v, p.row_max + b * p.width, p.row_lsum + b * p.width, parent, word);
+        if (p.alive_count) {          // early exit: beams of this image that go on (a slot without a valid winner counts as ended)
+            const bool on = tid < p.k && (unsigned)best.idx < (unsigned)(p.width * p.V) && p.alive_out[b * p.k + tid] != 0.0f;
+            const int cnt = __popcll(__ballot(on));
+            if (tid == 0 && cnt) atomicAdd(p.alive_count + p.t, cnt);
+        }
     }
     __syncthreads();
     beam_follow_winners<256>(p, b, tid, parent, word);
@@ -622,6 +627,12 @@ __global__ __launch_bounds__(kFusedThreads) void beam_fused_update_kernel(BeamUp
         p.next_tok[b * k + tid] = wd;
         p.anc_out[((size_t)b * k + tid) * T + t] = b * W + par;
     }
+    if (p.alive_count && wave == 0) {      // early exit: beams of this image that go on (no valid winner = ended: NaN logits)
+        const bool on = tid < k && (unsigned)win_i[tid] < (unsigned)(W * V) && rowLive[parent[tid]] &&
+                        p.alive_in[b * W + parent[tid]] != 0.0f && word[tid] != p.eos;
+        const int cnt = __popcll(__ballot(on));
+        if (tid == 0 && cnt) atomicAdd(p.alive_count + t, cnt);
+    }
     __syncthreads();
     beam_follow_winners<kFusedThreads>(p, b, tid, parent, word);
 }
@@ -653,11 +664,12 @@ __global__ __launch_bounds__(64) void beam_finalize_kernel(BeamFinalArgs p) {
         if (p.order_out) p.order_out[b * k + rank] = tid;
     }
     __syncthreads();
+    const int written = p.steps_run > 0 ? p.steps_run : T;     // early exit: later positions are word 0 / log-prob 0
     for (int idx = tid; idx < p.out_size * T; idx += 64) {
         const int o = idx / T, pos = idx - o * T;
         const size_t src = ((size_t)b * k + order[o]) * T + pos;
-        p.ids_out[((size_t)b * p.out_size + o) * T + pos] = (int64_t)p.hist[src];
-        p.logp_out[((size_t)b * p.out_size + o) * T + pos] = p.lp[src];
+        p.ids_out[((size_t)b * p.out_size + o) * T + pos] = pos < written ? (int64_t)p.hist[src] : (int64_t)0;
+        p.logp_out[((size_t)b * p.out_size + o) * T + pos] = pos < written ? p.lp[src] : 0.f;
     }
 }
 

@@ -228,6 +228,10 @@ struct BeamUpdateArgs {
     // input rows of step t + 1, written here instead of by a separate launch (nullptr: not wanted):
     //   next_x[b*k + j, :] = word_emb[word] + pos_emb[t + 2],  next_padflag[b*k + j] = (word == pad)
     const float* word_emb; const float* pos_emb; float* next_x; uint8_t* next_padflag; int d_model, pad;
+    // early exit (ovc_beam_search_early; nullptr otherwise): alive_count[t] receives, summed over the batch's images, the beams
+    // still alive after step t (an image without any valid candidate -- NaN logits: no region at all -- counts as ended);
+    // zeroed by the caller before the first step.  0 = every later step only appends word 0 / log-prob 0 to every beam.
+    int32_t* alive_count;
 };
 int ovc_beam_update_launch(const BeamUpdateArgs& p, int B, hipStream_t stream);
 // Selection + update in one launch from the vocabulary GEMM's block pieces (GemmArgs::stats, [rows][stats_ld] float2,
@@ -245,6 +249,8 @@ struct BeamFinalArgs {
     const float* running; const int32_t* hist; const float* lp;
     int k, T, out_size;
     int64_t* ids_out; float* logp_out; int32_t* order_out;
+    int steps_run;           // 0 = all T steps ran.  s in 1..T-1 (early exit: every beam had ended): positions s..T-1 were never
+                             // written and are emitted as word 0 / log-prob 0 -- what the remaining steps would have appended
 };
 int ovc_beam_finalize_launch(const BeamFinalArgs& p, int B, hipStream_t stream);
 int ovc_beam_gather_all_launch(const float* all_buf, const int* order, int B, int k, int T, int V, float* all_out,

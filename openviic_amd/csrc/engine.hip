@@ -16,6 +16,7 @@
 #include <cstdlib>
 #include <list>
 #include <map>
+#include <memory>
 #include <atomic>
 #include <mutex>
 #include <tuple>
@@ -110,6 +111,7 @@ struct Workspace {
     int32_t* tok; float* cand_v; int32_t* cand_i; float* row_max; float* row_lsum; int32_t* order;
     float* all_buf;
     int64_t* out_ids; float* out_logp;            // graph replay writes here, then copied to the caller
+    int32_t* alive_count;                         // [T] beams still alive after each step (ovc_beam_search_early)
     size_t bytes;
 };
 
@@ -182,6 +184,7 @@ Workspace carve(const ovc_model* m, void* base, int B, int N, int k, int return_
     w.row_max = a.take<float>(R); w.row_lsum = a.take<float>(R); w.order = a.take<int32_t>(R);
     w.all_buf = a.take<float>(return_probs ? T * R * (size_t)m->vocab : 0);
     w.out_ids = a.take<int64_t>(R * T); w.out_logp = a.take<float>(R * T);
+    w.alive_count = a.take<int32_t>(T);
     w.bytes = (a.off + 255) & ~(size_t)255;
     return w;
 }
@@ -454,7 +457,7 @@ int project_cross_kv(Engine& e, Workspace& w, int B, int N) {
     return OVC_OK;
 }
 
-int run_decode_step(Engine& e, Workspace& w, int B, int N, int k, int t, int return_probs) {
+int run_decode_step(Engine& e, Workspace& w, int B, int N, int k, int t, int return_probs, bool count_alive = false) {
     const ovc_model* m = e.m;
     hipStream_t s = e.stream;
     const int d = m->d_model, hk = m->heads * m->d_k, hv = m->heads * m->d_v, lv = m->n_levels, T = m->max_len;
@@ -598,6 +601,7 @@ int run_decode_step(Engine& e, Workspace& w, int B, int N, int k, int t, int ret
     bu.hist_in = w.hist[cur]; bu.hist_out = w.hist[nxt]; bu.lp_in = w.lp[cur]; bu.lp_out = w.lp[nxt];
     bu.anc_in = w.anc[cur]; bu.anc_out = w.anc[nxt]; bu.next_tok = w.tok;
     bu.width = width; bu.k = k; bu.V = m->vocab; bu.T = T; bu.t = t; bu.eos = m->eos_idx;
+    bu.alive_count = count_alive ? w.alive_count : nullptr;
     if (t + 1 < T) {
         bu.word_emb = m->word_emb; bu.pos_emb = m->pos_emb; bu.next_x = w.x; bu.next_padflag = w.padflag + (size_t)(t + 1) * R;
         bu.d_model = d; bu.pad = m->pad_idx;
@@ -624,7 +628,7 @@ int run_decode_step(Engine& e, Workspace& w, int B, int N, int k, int t, int ret
 
 }  // namespace
 
-extern "C" int ovc_abi_version(void) { return 6; }
+extern "C" int ovc_abi_version(void) { return 7; }     // 7: ovc_beam_search_early, ovc_debug_vocab_select(kchains), OVC_MAX_REGIONS
 
 extern "C" const char* ovc_build_info(void) {
 #ifdef OVC_MEASUREMENT_HOOKS
@@ -759,6 +763,17 @@ uint64_t hash_bytes(const void* p, size_t n) {
     return h;
 }
 
+// The stream launch sequences are captured on (never the caller's: see ovc_beam_search_graph).  One device per process
+// (ovc_device_guard): the stream belongs to the bound device.  Caller holds g_graph_mutex; nullptr = no capture support.
+hipStream_t private_capture_stream() {
+    static hipStream_t capture_stream = nullptr;
+    if (!capture_stream && hipStreamCreateWithFlags(&capture_stream, hipStreamNonBlocking) != hipSuccess) {
+        (void)hipGetLastError();
+        capture_stream = nullptr;
+    }
+    return capture_stream;
+}
+
 int issue_decode_graph_body(Engine& e, Workspace& w, int B, int N, int k, int out_size) {
     const ovc_model* m = e.m;
     const int R = B * k, T = m->max_len;
@@ -803,11 +818,8 @@ extern "C" int ovc_beam_search_graph(const ovc_model* m, const float* features, 
     // Kernel nodes carry no stream, so the instantiated graph is launched on the caller's stream as usual.
     // (The legacy null stream can launch a graph but offers nothing else here; it takes the same path.)
     if (!entry.unsupported && !g_profile_on && entry.calls > 1 && !entry.exec) {
-        // one device per process (ovc_device_guard above): the capture stream belongs to the bound device
-        static hipStream_t capture_stream = nullptr;          // guarded by g_graph_mutex
-        if (!capture_stream && hipStreamCreateWithFlags(&capture_stream, hipStreamNonBlocking) != hipSuccess) {
-            (void)hipGetLastError();
-            capture_stream = nullptr;
+        hipStream_t capture_stream = private_capture_stream();
+        if (!capture_stream) {
             entry.unsupported = true;
         } else if (hipStreamBeginCapture(capture_stream, hipStreamCaptureModeThreadLocal) != hipSuccess) {
             (void)hipGetLastError();
@@ -832,6 +844,150 @@ extern "C" int ovc_beam_search_graph(const ovc_model* m, const float* features, 
     }
     if (hipMemcpyAsync(ids_out, w.out_ids, sizeof(int64_t) * out_n, hipMemcpyDeviceToDevice, e.stream) != hipSuccess) return OVC_ELAUNCH;
     if (hipMemcpyAsync(logp_out, w.out_logp, sizeof(float) * out_n, hipMemcpyDeviceToDevice, e.stream) != hipSuccess) return OVC_ELAUNCH;
+    return OVC_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Early exit (round 4).  The reference always runs max_len steps (beam_search.py:94-95), although once every beam of every
+// image has emitted <eos> a step only appends word 0 / log-prob 0 to every beam and (once) re-orders the beams by score --
+// which the final ordering does anyway (beam_search.py:49-55, 97-113).  Here the update kernel of step t leaves the number of
+// beams still alive in alive_count[t]; the host issues the search STEP BY STEP (one captured graph per step), copies that word
+// to pinned memory behind each step and looks at it one step late -- the GPU always has the next step queued -- and stops
+// issuing steps once it reads 0.  The final ordering then emits word 0 / log-prob 0 for the positions that were never
+// written: results are identical to the full run (tests/test_engine_gpu.py::test_early_exit_*).  Assumes no total score
+// below -999 (a frozen beam's other candidates, beam_search.py:54).
+// ---------------------------------------------------------------------------------------------
+namespace {
+struct EarlyEntry {
+    int calls = 0;
+    bool unsupported = false;
+    hipGraph_t prologue_graph = nullptr; hipGraphExec_t prologue_exec = nullptr;
+    std::vector<hipGraph_t> step_graph; std::vector<hipGraphExec_t> step_exec;
+    std::vector<hipEvent_t> step_done;
+    int32_t* host_alive = nullptr;                 // pinned [T]
+    hipStream_t last_stream = nullptr;
+    uint64_t last_use = 0;
+    std::mutex in_use;                             // one search at a time per (model, shape, workspace)
+    ~EarlyEntry() {
+        if (last_stream) (void)hipStreamSynchronize(last_stream);
+        for (hipGraphExec_t x : step_exec) if (x) (void)hipGraphExecDestroy(x);
+        for (hipGraph_t g : step_graph) if (g) (void)hipGraphDestroy(g);
+        if (prologue_exec) (void)hipGraphExecDestroy(prologue_exec);
+        if (prologue_graph) (void)hipGraphDestroy(prologue_graph);
+        for (hipEvent_t ev : step_done) if (ev) (void)hipEventDestroy(ev);
+        if (host_alive) (void)hipHostFree(host_alive);
+    }
+};
+std::map<GraphKey, std::shared_ptr<EarlyEntry>> g_early;        // guarded by g_graph_mutex
+
+int issue_early_prologue(Engine& e, Workspace& w, int B, int N, int k) {
+    const int R = B * k;
+    TRY(run_encoder_layers(e, w, B, N));
+    TRY(project_cross_kv(e, w, B, N));
+    hipLaunchKernelGGL(init_beam_state_kernel, dim3((R + 255) / 256), dim3(256), 0, e.stream, w.running[0], w.alive[0], R);
+    OVC_RETURN_IF_LAUNCH_FAILED();
+    if (hipMemsetAsync(w.alive_count, 0, sizeof(int32_t) * e.m->max_len, e.stream) != hipSuccess) return OVC_ELAUNCH;
+    return OVC_OK;
+}
+
+// Capture `issue` on the private stream into (graph, exec); false = capture not available (the caller launches plainly).
+template <typename Issue>
+bool capture_into(hipGraph_t* graph, hipGraphExec_t* exec, const ovc_model* m, Issue issue) {
+    hipStream_t cs = private_capture_stream();
+    if (!cs || hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal) != hipSuccess) { (void)hipGetLastError(); return false; }
+    Engine ce{m, cs, 0};
+    const int rc = issue(ce);
+    const hipError_t end = hipStreamEndCapture(cs, graph);
+    if (rc != OVC_OK || end != hipSuccess || !*graph || hipGraphInstantiate(exec, *graph, nullptr, nullptr, 0) != hipSuccess) {
+        (void)hipGetLastError();
+        if (*graph) (void)hipGraphDestroy(*graph);
+        *graph = nullptr; *exec = nullptr;
+        return false;
+    }
+    return true;
+}
+}  // namespace
+
+extern "C" int ovc_beam_search_early(const ovc_model* m, const float* features, const float* boxes, int B, int N, int k,
+                                     int out_size, void* workspace, size_t workspace_bytes, int64_t* ids_out,
+                                     float* logp_out, int* steps_run_out, ovc_stream stream) {
+    if (!model_ok(m) || !features || !workspace || !ids_out || !logp_out) return OVC_EINVAL;
+    TRY(ovc_device_guard());
+    if (B <= 0 || N <= 0 || N > OVC_MAX_REGIONS || k <= 0 || k > OVC_MAX_BEAM || out_size <= 0 || out_size > k) return OVC_EINVAL;
+    if ((long)m->vocab < k) return OVC_EINVAL;
+    if (!ovc_aligned16(features) || !ovc_aligned16(workspace)) return OVC_EINVAL;
+    Workspace w = carve(m, workspace, B, N, k, 0);
+    if (w.bytes > workspace_bytes) return OVC_EWORKSPACE;
+    Engine e{m, ovc_hip_stream(stream), 0};
+    const int T = m->max_len;
+
+    std::shared_ptr<EarlyEntry> entry;
+    {
+        const GraphKey key{hash_bytes(m, sizeof(*m)), workspace, B, N, k, out_size};
+        std::lock_guard<std::mutex> lock(g_graph_mutex);
+        std::shared_ptr<EarlyEntry>& slot = g_early[key];
+        if (!slot) slot = std::make_shared<EarlyEntry>();
+        entry = slot;
+        entry->last_use = ++g_graph_tick;
+        while (g_early.size() > graph_cache_capacity()) {          // least recently used first; an entry in use lives on in its caller
+            auto victim = g_early.end();
+            for (auto it = g_early.begin(); it != g_early.end(); ++it)
+                if (it->second != entry && (victim == g_early.end() || it->second->last_use < victim->second->last_use)) victim = it;
+            if (victim == g_early.end()) break;
+            g_early.erase(victim);
+        }
+    }
+    std::lock_guard<std::mutex> busy(entry->in_use);
+    entry->calls += 1;
+    entry->last_stream = e.stream;
+    if (!entry->host_alive) {
+        if (hipHostMalloc(reinterpret_cast<void**>(&entry->host_alive), sizeof(int32_t) * T, hipHostMallocDefault) != hipSuccess) {
+            (void)hipGetLastError();
+            entry->host_alive = nullptr;
+            return OVC_ELAUNCH;
+        }
+        entry->step_graph.assign(T, nullptr); entry->step_exec.assign(T, nullptr); entry->step_done.assign(T, nullptr);
+        for (int t = 0; t < T; ++t)
+            if (hipEventCreateWithFlags(&entry->step_done[t], hipEventDisableTiming) != hipSuccess) return OVC_ELAUNCH;
+    }
+    const bool graphs = !entry->unsupported && !g_profile_on && entry->calls > 1;   // first call of a shape: plain (warms every kernel)
+
+    TRY(run_encoder_inputs(e, w, features, boxes, B, N));
+    if (graphs && !entry->prologue_exec) {
+        std::lock_guard<std::mutex> lock(g_graph_mutex);           // the capture stream is shared process-wide
+        if (!capture_into(&entry->prologue_graph, &entry->prologue_exec, m, [&](Engine& ce) { return issue_early_prologue(ce, w, B, N, k); }))
+            entry->unsupported = true;
+    }
+    if (graphs && entry->prologue_exec) { if (hipGraphLaunch(entry->prologue_exec, e.stream) != hipSuccess) return OVC_ELAUNCH; }
+    else TRY(issue_early_prologue(e, w, B, N, k));
+
+    int steps_run = T;
+    for (int t = 0; t < T; ++t) {
+        if (graphs && !entry->unsupported && !entry->step_exec[t]) {
+            std::lock_guard<std::mutex> lock(g_graph_mutex);
+            if (!capture_into(&entry->step_graph[t], &entry->step_exec[t], m,
+                              [&](Engine& ce) { return run_decode_step(ce, w, B, N, k, t, 0, true); }))
+                entry->unsupported = true;
+        }
+        if (graphs && entry->step_exec[t]) { if (hipGraphLaunch(entry->step_exec[t], e.stream) != hipSuccess) return OVC_ELAUNCH; }
+        else TRY(run_decode_step(e, w, B, N, k, t, 0, true));
+        if (t + 1 == T) break;                                      // nothing left to skip
+        if (hipMemcpyAsync(entry->host_alive + t, w.alive_count + t, sizeof(int32_t), hipMemcpyDeviceToHost, e.stream) != hipSuccess ||
+            hipEventRecord(entry->step_done[t], e.stream) != hipSuccess) return OVC_ELAUNCH;
+        // one step late: step t is queued, step t - 1's count is (about to be) on the host
+        if (t >= 1) {
+            if (hipEventSynchronize(entry->step_done[t - 1]) != hipSuccess) return OVC_ELAUNCH;
+            if (entry->host_alive[t - 1] == 0) { steps_run = t + 1; break; }
+        }
+    }
+
+    const int fin = steps_run & 1;
+    BeamFinalArgs bf{};
+    bf.running = w.running[fin]; bf.hist = w.hist[fin]; bf.lp = w.lp[fin];
+    bf.k = k; bf.T = T; bf.out_size = out_size; bf.ids_out = ids_out; bf.logp_out = logp_out; bf.order_out = w.order;
+    bf.steps_run = steps_run < T ? steps_run : 0;
+    TRY(ovc_beam_finalize_launch(bf, B, e.stream));
+    if (steps_run_out) *steps_run_out = steps_run;
     return OVC_OK;
 }
 
@@ -884,6 +1040,7 @@ extern "C" int ovc_graph_cache_clear(void) {
     std::lock_guard<std::mutex> lock(g_graph_mutex);
     for (auto& kv : g_graphs) destroy_entry(kv.second);
     g_graphs.clear();
+    g_early.clear();
     return OVC_OK;
 }
 
@@ -894,12 +1051,16 @@ extern "C" int ovc_graph_cache_drop_workspace(const void* workspace) {
         if (it->first.ws == workspace) { destroy_entry(it->second); it = g_graphs.erase(it); ++dropped; }
         else ++it;
     }
+    for (auto it = g_early.begin(); it != g_early.end();) {
+        if (it->first.ws == workspace) { it = g_early.erase(it); ++dropped; }
+        else ++it;
+    }
     return dropped;
 }
 
 extern "C" int ovc_graph_cache_size(void) {
     std::lock_guard<std::mutex> lock(g_graph_mutex);
-    return (int)g_graphs.size();
+    return (int)(g_graphs.size() + g_early.size());
 }
 
 extern "C" int ovc_profile_enable(int on) {

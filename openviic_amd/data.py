@@ -62,8 +62,46 @@ def batch_from_feature_files(paths: Sequence[str], keys: Optional[Iterable[str]]
     return batch.to(device) if device is not None else batch
 
 
+class FeatureFileDataset:
+    """Map-style dataset over per-image feature files -- the reference's ``DictionaryDataset`` reduced to what the prediction
+    loop reads (``data_utils/dataset.py:74-127``: ``load_features`` per item): item i = the fields of ``paths[i]`` as numpy
+    arrays plus ``filename``.  Picklable (a list of paths), so ``torch.utils.data.DataLoader`` workers can hold it."""
+
+    def __init__(self, paths: Sequence[str], keys: Optional[Iterable[str]] = None, trusted: bool = False):
+        self.paths = list(paths)
+        self.keys = tuple(keys) if keys is not None else None
+        self.trusted = trusted
+
+    def __len__(self) -> int:
+        return len(self.paths)
+
+    def __getitem__(self, index: int) -> dict:
+        return _fields_from_file(self.paths[index], self.keys, self.trusted)
+
+
+def collate_feature_fields(items: Sequence[dict]) -> dict:
+    """The reference's collate (``data_utils/utils.py:120-121`` -> ``InstanceList``: ragged region counts zero-padded) as a
+    ``DataLoader`` ``collate_fn``.  Returns a PLAIN dict (name -> tensor or list): a worker hands its tensors to the parent
+    through shared memory and the loader's pinning thread walks dicts; ``InstanceList(...)`` is rebuilt by the consumer."""
+    return dict(InstanceList([Instance(**fields) for fields in items]))
+
+
+def feature_file_loader(paths: Sequence[str], batch_size: int, workers: int, keys: Optional[Iterable[str]] = None,
+                        trusted: bool = False, pin_memory: bool = True, prefetch_factor: int = 2, context=None):
+    """``DataLoader`` over feature files the way the reference feeds its loops (``trainers/base_trainer.py:40-80``: worker
+    processes, ``collate_fn``): consecutive groups of ``batch_size`` paths, in order, each batch read and collated by ONE worker
+    process and handed over through shared memory (a 105 MB batch at B = 256 is not pickled through a pipe: that is what
+    capped round 3's reader pool at 350 MB/s), then copied into pinned memory by the loader's pinning thread."""
+    from torch.utils.data import DataLoader
+    return DataLoader(FeatureFileDataset(paths, keys, trusted), batch_size=batch_size, shuffle=False, num_workers=workers,
+                      collate_fn=collate_feature_fields, pin_memory=pin_memory and workers > 0,
+                      prefetch_factor=prefetch_factor if workers > 0 else None,
+                      multiprocessing_context=context if workers > 0 else None, persistent_workers=False)
+
+
 def predict_feature_files(model, vocab, paths: Sequence[str], batch_size: int, beam_size: int = 5, slots: int = 2,
-                          keys: Optional[Iterable[str]] = None, trusted: bool = False):
+                          keys: Optional[Iterable[str]] = None, trusted: bool = False, workers: int = 0,
+                          loader_context=None):
     """The reference's prediction loop (``trainers/vi_trainer.py:241-252``: per batch ``items.to(device)`` ->
     ``model.beam_search(items, batch_size, beam_size, out_size=1)`` -> ``decode_caption`` -> duplicate collapse) as a
     software pipeline on ONE host thread:
@@ -82,6 +120,12 @@ def predict_feature_files(model, vocab, paths: Sequence[str], batch_size: int, b
     for the test set and ``DICT_BATCH_SIZE // beam`` for validation, ``trainers/base_trainer.py:63-80``).  Returns
     ``[(filename, caption)]`` in input order; results are identical to the sequential loop
     (``tests/test_engine_gpu.py::test_pipelined_prediction_matches_the_sequential_loop``).
+
+    ``workers > 0`` (round 4): the host side of the loop -- parsing the feature files and collating a batch, Python work that
+    one thread does at 600-880 images/s -- moves into ``workers`` ``DataLoader`` processes (``feature_file_loader``); batches
+    arrive already pinned and go straight to the copy stream.  Same strings, in the same order.  ``loader_context``: the
+    ``multiprocessing`` start method of the workers (``None`` = the platform default, fork; ``"spawn"`` starts clean
+    interpreters, a few seconds slower to come up).
     """
     import torch
 
@@ -104,7 +148,7 @@ def predict_feature_files(model, vocab, paths: Sequence[str], batch_size: int, b
     def finish(slot):
         entry, pending[slot] = pending[slot], None
         if entry is not None:
-            names, ids_host, done = entry
+            names, ids_host, done, _host_batch = entry        # the host batch (pinned source of the async copy) lived until here
             done.synchronize()
             results.extend(zip(names, captions_from_ids(vocab, ids_host)))
 
@@ -117,10 +161,18 @@ def predict_feature_files(model, vocab, paths: Sequence[str], batch_size: int, b
             buf = pinned[slot][name] = torch.empty(max(numel, 1), dtype=dtype).pin_memory()
         return buf[:numel].view(tuple(shape))
 
+    if workers > 0:
+        source = iter(feature_file_loader(paths, batch_size, workers, keys=keys, trusted=trusted, context=loader_context))
+    else:
+        source = (batch_from_feature_files(paths[first:first + batch_size], keys=keys, trusted=trusted)
+                  for first in range(0, len(paths), batch_size))
     index = 0
     with torch.no_grad():
-        for first in range(0, len(paths), batch_size):
-            host = batch_from_feature_files(paths[first:first + batch_size], keys=keys, trusted=trusted)
+        for host in source:
+            if not isinstance(host, InstanceList):
+                fields, host = host, InstanceList()
+                for name, value in fields.items():
+                    host[name] = value
             slot = index % slots
             index += 1
             finish(slot)                               # the slot's pinned buffers are free again once its last batch is done
@@ -128,8 +180,11 @@ def predict_feature_files(model, vocab, paths: Sequence[str], batch_size: int, b
             with torch.cuda.stream(copy_stream):
                 for name, value in host.items():
                     if isinstance(value, torch.Tensor):
-                        stage = pinned_like(slot, name, value.shape, value.dtype)
-                        stage.copy_(value)
+                        if value.is_pinned():          # from the loader's pinning thread: no staging copy (kept alive below)
+                            stage = value
+                        else:
+                            stage = pinned_like(slot, name, value.shape, value.dtype)
+                            stage.copy_(value)
                         dev = stage.to(device, non_blocking=True)
                         dev.record_stream(decode_streams[slot])
                         items[name] = dev
@@ -144,7 +199,7 @@ def predict_feature_files(model, vocab, paths: Sequence[str], batch_size: int, b
                 ids_host.copy_(outs, non_blocking=True)
                 done = torch.cuda.Event()
                 done.record(decode_streams[slot])
-            pending[slot] = (list(host["filename"]) if "filename" in host else [None] * items.batch_size, ids_host, done)
+            pending[slot] = (list(host["filename"]) if "filename" in host else [None] * items.batch_size, ids_host, done, host)
     for step in range(slots):                          # oldest first
         finish((index + step) % slots)
     return results

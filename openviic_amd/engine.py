@@ -118,6 +118,11 @@ class CaptionEngine:
     # workgroup of every launch -- same bits, W then bypasses conversion and LDS (OVC_PRECUT_WEIGHTS=0: A/B switch)
     precut_weights = os.environ.get("OVC_PRECUT_WEIGHTS", "1") != "0"
     precision = os.environ.get("OVC_PRECISION", "f32")
+    # stop issuing decode steps once every beam of every image has ended (ovc_beam_search_early: identical results, but the call
+    # blocks the host thread until the search is one step from its end -- use one host thread per stream to overlap batches).
+    # Pays for real captions (they end well before max_len); random-weight benchmarks never emit <eos>.  Per call:
+    # beam_search(..., early_exit=True).
+    early_exit = os.environ.get("OVC_EARLY_EXIT", "0") != "0"
 
     def __init__(self, model, tune_concurrency=None, precision=None):
         self.lib = native.load()
@@ -374,7 +379,9 @@ class CaptionEngine:
             raise native.OvcError("the geometric encoder needs region boxes")
         return features, boxes
 
-    def beam_search(self, features, boxes, batch_size, beam_size, out_size=1, return_probs=False):
+    def beam_search(self, features, boxes, batch_size, beam_size, out_size=1, return_probs=False, early_exit=None):
+        """``early_exit`` (default: the class attribute / OVC_EARLY_EXIT): see above; ``self.last_steps_run`` then holds the
+        number of decode steps that were issued for the call."""
         features, boxes = self._checked_inputs(features, boxes)
         features, boxes = self._bucketed(features, boxes)
         B, N = features.shape[:2]
@@ -389,7 +396,16 @@ class CaptionEngine:
         ids = torch.empty(B, out_size, T, dtype=torch.int64, device=self.device)
         logp = torch.empty(B, out_size, T, dtype=torch.float32, device=self.device)
         everything = torch.empty(B, beam_size, T, V, dtype=torch.float32, device=self.device) if return_probs else None
-        if self.use_graph and not return_probs:
+        early = self.early_exit if early_exit is None else bool(early_exit)
+        self.last_steps_run = T
+        if early and not return_probs:
+            steps = ctypes.c_int(0)
+            check(self.lib.ovc_beam_search_early(ctypes.byref(d), features.data_ptr(),
+                                                 None if boxes is None else boxes.data_ptr(), B, N, beam_size, out_size,
+                                                 ws.data_ptr(), need, ids.data_ptr(), logp.data_ptr(), ctypes.byref(steps),
+                                                 native.stream_handle()), "ovc_beam_search_early")
+            self.last_steps_run = steps.value
+        elif self.use_graph and not return_probs:
             check(self.lib.ovc_beam_search_graph(ctypes.byref(d), features.data_ptr(),
                                                  None if boxes is None else boxes.data_ptr(), B, N, beam_size, out_size,
                                                  ws.data_ptr(), need, ids.data_ptr(), logp.data_ptr(),

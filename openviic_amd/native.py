@@ -13,7 +13,7 @@ OVC_MAX_LEVELS = 4
 OVC_MAX_BEAM = 8
 OVC_MAX_REGIONS = 1024
 OVC_PROFILE_CLASSES = 4
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 _ERRORS = {-1: "OVC_EINVAL (bad argument / unsupported shape)", -2: "OVC_EWORKSPACE (workspace too small)",
            -3: "OVC_ELAUNCH (HIP launch failed)",
@@ -114,6 +114,8 @@ SIGNATURES = {
     "ovc_debug_repeat_linear": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "ovc_beam_search_graph": (c_int, [POINTER(Model), c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_size_t,
                                       c_void_p, c_void_p, c_void_p]),
+    "ovc_beam_search_early": (c_int, [POINTER(Model), c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_size_t,
+                                      c_void_p, c_void_p, POINTER(c_int), c_void_p]),
     "ovc_graph_cache_clear": (c_int, []),
     "ovc_profile_enable": (c_int, [c_int]),
     "ovc_profile_read": (c_int, [c_int, c_int, POINTER(c_int64), POINTER(c_double), POINTER(c_double)]),

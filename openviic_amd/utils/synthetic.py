@@ -96,6 +96,27 @@ def synthetic_state_dict(template: Mapping[str, torch.Tensor], seed: int = 1234,
     return out
 
 
+def eos_biased_state_dict(state_dict: Mapping[str, torch.Tensor], template: Mapping[str, torch.Tensor], eos_idx: int = 2,
+                          ramp: float = 2.0, gain: float = 3.0, mid: int = 10, seed: int = 5) -> Dict[str, torch.Tensor]:
+    """Synthetic weights whose captions END at realistic lengths.  Random-init weights never emit ``<eos>``,
+    so nothing about finished beams -- the -999 branch, early exit -- shows on them.  Here the decoder's position table (a
+    ``state_dict`` entry: ``decoder.pos_emb.weight``, taken from ``template``, the model's own ``state_dict()``) gets a component
+    ``ramp * (t - mid) * u`` along a fixed unit direction ``u``, and the ``<eos>`` row of the vocabulary projection is ``gain * u``:
+    the ``<eos>`` logit rises with the position and the beams end around step ``mid`` (with the defaults and a 2-layer d = 128
+    model: between steps 6 and 12, mean 9).  Returns a copy; works for the oracle and the product alike."""
+    out = {k: v.clone() for k, v in state_dict.items()}
+    pos = template["decoder.pos_emb.weight"].detach().clone().float().cpu()
+    g = torch.Generator().manual_seed(seed)
+    u = torch.randn(pos.shape[1], generator=g)
+    u = u / u.norm()
+    steps = torch.arange(pos.shape[0], dtype=torch.float32)[:, None]
+    out["decoder.pos_emb.weight"] = pos + ramp * (steps - mid) * u
+    fc = out["decoder.fc.weight"].clone()
+    fc[eos_idx] = gain * u
+    out["decoder.fc.weight"] = fc
+    return out
+
+
 def synthetic_features(batch: int, regions: int = 50, d_feature: int = 2048, seed: int = 0,
                        ragged: bool = False) -> torch.Tensor:
     """``randn(B, N, d)`` from a CPU generator; ``ragged`` zero-pads tails."""

@@ -54,12 +54,12 @@ def grid_visibility_mask(boxes: Tensor, grid_size: int) -> Tensor:
 
 
 def normalized_position_encoding(batch: int, n: int, d_model: int, temperature: float = 10000.0,
-                                 scale: float = 2 * math.pi) -> Tensor:
+                                 scale: float = 2 * math.pi, dtype: torch.dtype = torch.float32) -> Tensor:
     """models/modules/pos_embeddings.py:58-72 with mask=None, normalize=True: position i+1 is divided by
     (n + 1e-6) and multiplied by ``scale`` before the sinusoids."""
-    position = torch.ones(batch, n).cumsum(1, dtype=torch.float32)
+    position = torch.ones(batch, n).cumsum(1, dtype=dtype)
     position = position / (position[:, -1:] + 1e-6) * scale
-    channel = torch.arange(d_model, dtype=torch.float32)
+    channel = torch.arange(d_model, dtype=dtype)
     divisor = temperature ** (2 * torch.div(channel, 2, rounding_mode="floor") / d_model)
     angle = position[:, :, None] / divisor
     return torch.stack((angle[:, :, 0::2].sin(), angle[:, :, 1::2].cos()), dim=-1).flatten(-2)
@@ -68,9 +68,12 @@ def normalized_position_encoding(batch: int, n: int, d_model: int, temperature: 
 class OracleDualEncoder(OracleCaptioner):
     """``embedding_sd`` / ``encoder_sd`` are the state_dicts of the two reference modules."""
 
-    def __init__(self, encoder_cfg: Any, embedding_sd: Dict[str, Tensor], encoder_sd: Dict[str, Tensor]):
-        self.sd = {"emb." + k: v.detach().float().cpu() for k, v in embedding_sd.items()}
-        self.sd.update({"enc." + k: v.detach().float().cpu() for k, v in encoder_sd.items()})
+    def __init__(self, encoder_cfg: Any, embedding_sd: Dict[str, Tensor], encoder_sd: Dict[str, Tensor],
+                 dtype: torch.dtype = torch.float32):
+        # dtype = float64: the conditioning yardstick of OracleCaptioner (masks are still found on the fp32 inputs)
+        self.dtype = dtype
+        self.sd = {"emb." + k: v.detach().to(dtype).cpu() for k, v in embedding_sd.items()}
+        self.sd.update({"enc." + k: v.detach().to(dtype).cpu() for k, v in encoder_sd.items()})
         self.cfg = encoder_cfg
         self.trace = None
         self.d_model = int(_get(encoder_cfg, "D_MODEL"))
@@ -88,13 +91,13 @@ class OracleDualEncoder(OracleCaptioner):
         r2g = grid_visibility_mask(region_boxes, int(gg ** 0.5))
         region2all = torch.cat([region_mask.expand(bsz, 1, n, n), r2g], dim=-1)
         grid2all = torch.cat([r2g.permute(0, 1, 3, 2), grid_mask.expand(bsz, 1, gg, gg)], dim=-1)
-        return ((self._lin("emb.region_proj", region), region_mask), (self._lin("emb.grid_proj", grid), grid_mask),
-                (region2all, grid2all))
+        return ((self._lin("emb.region_proj", region.to(self.dtype)), region_mask),
+                (self._lin("emb.grid_proj", grid.to(self.dtype)), grid_mask), (region2all, grid2all))
 
     def geometry(self, boxes: Tensor) -> Tensor:
         """encoders.py:157-164."""
         d_g = self.d_model // self.heads if self.trig else 4
-        emb = box_relation_features(boxes, dim_g=d_g, trignometric=self.trig)
+        emb = box_relation_features(boxes.to(self.dtype), dim_g=d_g, trignometric=self.trig)
         b, n = emb.shape[:2]
         per_head = [self._lin("enc.fc_gs.%d" % i, emb.view(-1, d_g)).view(b, 1, n, n) for i in range(self.heads)]
         return F.relu(torch.cat(per_head, dim=1))
@@ -107,7 +110,7 @@ class OracleDualEncoder(OracleCaptioner):
         self._note("geometry_weights", w)
 
         def pe(x):
-            return normalized_position_encoding(x.shape[0], x.shape[1], self.d_model)
+            return normalized_position_encoding(x.shape[0], x.shape[1], self.d_model, dtype=self.dtype)
 
         def layer(prefix, cfg, q, kv, geo, mask, q_pad):
             att = self.multi_head(prefix + ".mhatt", cfg, q, kv, kv, mask, geo)

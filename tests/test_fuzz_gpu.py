@@ -54,6 +54,7 @@ def test_random_architectures_and_shapes_against_the_oracle():
     cases = int(os.environ.get("OVC_FUZZ_CASES", "40"))
     rng = random.Random(int(os.environ.get("OVC_FUZZ_SEED", "20261004")))
     checked_images = decided_total = refused = 0
+    worst_conditioning = 0.0
     for case in range(cases):
         variant, dims, (B, N, V, T, k), trig = _draw(rng)
         what = "case {}: {} {} B={} N={} V={} T={} k={} trig={}".format(case, variant, dims, B, N, V, T, k, trig)
@@ -86,14 +87,22 @@ def test_random_architectures_and_shapes_against_the_oracle():
         if variant == "object_relation_transformer":
             # The geometry bias is log(clamp(relu(fc_g(box relations)), 1e-6)) (attentions.py:97-114): next to the ReLU's zero a
             # rounding-level change of fc_g's output moves the bias by O(1), and the trigonometric embedding takes sin / cos of
-            # angles up to ~700 rad (one ulp of the angle: 6e-5).  Any two fp32 implementations differ in a few elements there,
-            # so this encoder is held to a norm: relative L2 error of the whole output; element-wise only a coarse sanity bound
-            # (1 element in 70 000 was seen 2e-3 off in 3 000 cases).  With the trigonometric embedding the box-relation weights
-            # themselves differ by up to 4e-5 between two fp32 implementations (log-ratios up to 6.9 times 100 times the frequency:
-            # one ulp of the logarithm is 5e-5 in the angle), and a weight of 1e-3 next to the ReLU's zero then moves the bias by
-            # 0.1: relative L2 errors up to 1.4e-3 were seen (1 case in 4 000); the bound is 3e-3.
-            err = np.linalg.norm(got_enc - ref_enc) / max(np.linalg.norm(ref_enc), 1e-12)
-            assert err < (3e-3 if trig else 5e-5), "{}: relative L2 error {:.2e}".format(what, err)
+            # angles up to ~700 rad (one fp32 ulp of the angle: 6e-5).  This encoder is ill-conditioned, so it is held to a
+            # CONDITIONING statement instead of a constant (the constant had grown 3e-4 -> 3e-3 on an
+            # argument): the same operation sequence in fp64 on the same fp32 weights and inputs is the yardstick, and the HIP
+            # result may be no further from it than twice what the reference's own fp32 arithmetic (the oracle) is --
+            #     ||HIP - fp64|| <= max(floor, 2 ||oracle_fp32 - fp64||)        (relative L2 norms of the encoder output)
+            # with a floor where both are at rounding level (1e-4 trigonometric, 1e-5 plain).  Measured on 400 + 150 random
+            # models (tools/trig_conditioning_probe.py, profiles/r04_trig_conditioning.txt): the two fp32 results sit equally far
+            # from fp64 -- medians 1.72e-5 / 1.62e-5, maxima 9.2e-4 / 1.07e-3 with the trigonometric embedding, 4e-7 / 1e-5
+            # without; wherever the HIP error exceeds 1e-4 the ratio is 0.85 .. 1.39.  Element-wise only a coarse sanity bound
+            # (a handful of elements per thousand sit next to the ReLU's zero).
+            ref64 = OracleCaptioner(cfg, sd, V, T, dtype=torch.float64).encode(feats, boxes)[0].numpy()[live]
+            scale = max(np.linalg.norm(ref64), 1e-300)
+            e_hip, e_cpu = np.linalg.norm(got_enc - ref64) / scale, np.linalg.norm(ref_enc - ref64) / scale
+            floor = 1e-4 if trig else 1e-5
+            assert e_hip <= max(floor, 2.0 * e_cpu), "{}: HIP {:.2e} from the fp64 result, the fp32 oracle {:.2e}".format(what, e_hip, e_cpu)
+            worst_conditioning = max(worst_conditioning, e_cpu)
             np.testing.assert_allclose(got_enc, ref_enc, rtol=5e-2, atol=2e-2, err_msg=what)
         else:
             np.testing.assert_allclose(got_enc, ref_enc, rtol=2e-4, atol=2e-5, err_msg=what)
@@ -127,8 +136,9 @@ def test_random_architectures_and_shapes_against_the_oracle():
                                        err_msg=what + " (return_probs)")
             assert torch.equal(ids_1, ids_k[:, 0]) and torch.equal(logp_1, logp_k[:, 0]), what + " (out_size = 1)"
         model._engine.release()
-    print("[fuzz] {} cases ({} refused up front), {} images, {} decided ({:.0f} %)".format(
-        cases, refused, checked_images, decided_total, 100.0 * decided_total / max(1, checked_images)))
+    print("[fuzz] {} cases ({} refused up front), {} images, {} decided ({:.0f} %); worst-conditioned object-relation encoder: "
+          "fp32 oracle {:.1e} from fp64".format(cases, refused, checked_images, decided_total,
+                                                100.0 * decided_total / max(1, checked_images), worst_conditioning))
     assert decided_total >= 0.5 * checked_images
 
 
@@ -207,5 +217,12 @@ def test_random_dual_collaborative_encoders_against_the_oracle():
         assert torch.equal(r2a.cpu(), or2a) and torch.equal(g2a.cpu(), og2a) and torch.equal(mask.cpu(), want_mask), what
         got, ref = out.cpu().numpy(), want.numpy()
         keep = np.isfinite(ref).all(axis=-1)                        # a row whose every key is masked is NaN in the reference
-        err = np.linalg.norm(got[keep] - ref[keep]) / max(np.linalg.norm(ref[keep]), 1e-12)
-        assert err < (3e-3 if trig else 5e-5), "{}: relative L2 error {:.2e}".format(what, err)
+        # the same conditioning statement as for the object-relation encoder above: fp64 on the same weights and inputs is the
+        # yardstick, the HIP result may be at most twice as far from it as the fp32 oracle is (floors at rounding level)
+        orc64 = OracleDualEncoder(enc_cfg, emb_sd, enc_sd, dtype=torch.float64)
+        (orf64, _), (ogf64, _), _ = orc64.embed(region, region_boxes, grid_f, grid_boxes)
+        ref64 = orc64.encode(orf64, region_boxes, orm, or2a, ogf64, grid_boxes, ogm, og2a)[0].numpy()
+        scale = max(np.linalg.norm(ref64[keep]), 1e-300)
+        e_hip, e_cpu = np.linalg.norm(got[keep] - ref64[keep]) / scale, np.linalg.norm(ref[keep] - ref64[keep]) / scale
+        assert e_hip <= max(1e-4 if trig else 1e-5, 2.0 * e_cpu), "{}: HIP {:.2e} from the fp64 result, the fp32 oracle {:.2e}".format(what, e_hip, e_cpu)
+        np.testing.assert_allclose(got[keep], ref[keep], rtol=5e-2, atol=2e-2, err_msg=what)

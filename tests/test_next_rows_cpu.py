@@ -148,3 +148,33 @@ def test_dual_collaborative_modules_register_and_match_reference_state_dict_surf
     assert {"layer_norm_region.weight", "layer_norm_grid.bias", "fc_gs.3.weight", "fc_gs.0.bias"} <= keys
     assert len(keys) == 4 + 2 * 4 + 4 * 2 * 16
     assert enc.state_dict()["fc_gs.0.weight"].shape == (1, 4)
+
+
+def test_feature_file_loader_collates_like_the_sequential_loop(tmp_path):
+    """SURVEY.md section 8f rank 2 / VERDICT r3 item 8: the DataLoader over feature files (worker processes, the reference's way
+    of feeding its loops: trainers/base_trainer.py:40-80) must hand over exactly the batches the sequential collate builds --
+    same order, same zero padding of ragged region counts, same non-tensor fields -- including the ragged last batch."""
+    import numpy as np
+    import torch
+    from openviic_amd.data import batch_from_feature_files, collate_feature_fields, feature_file_loader, FeatureFileDataset
+    g = torch.Generator().manual_seed(1)
+    paths = []
+    for i in range(11):
+        n = int(torch.randint(3, 8, (1,), generator=g))
+        path = str(tmp_path / ("img_%02d.npz" % i))
+        np.savez(path, region_features=torch.randn(n, 32, generator=g).numpy(), region_boxes=torch.rand(n, 4, generator=g).numpy())
+        paths.append(path)
+    assert len(FeatureFileDataset(paths)) == 11 and sorted(FeatureFileDataset(paths, keys=("region_boxes",))[3]) == ["filename", "region_boxes"]
+    for workers in (0, 2):
+        got = list(feature_file_loader(paths, 4, workers, pin_memory=False))
+        assert len(got) == 3
+        for i, fields in enumerate(got):
+            want = batch_from_feature_files(paths[4 * i:4 * i + 4])
+            assert isinstance(fields, dict) and list(fields) == list(want)
+            for name in want:
+                if isinstance(want[name], torch.Tensor):
+                    assert torch.equal(fields[name], want[name]), (workers, i, name)
+                else:
+                    assert fields[name] == want[name]
+    single = collate_feature_fields([FeatureFileDataset(paths)[0]])
+    assert single["region_features"].shape[0] == 1 and single["filename"] == ["img_00.npz"]

@@ -552,6 +552,7 @@ def test_tuner_only_ranks_inside_the_class_and_borrows_neighbouring_shapes():
     lib = native.load()
     M, N, K = 192, 256, 128
     scratch = torch.randn(4 * (M * K + N * K + 4 * M * N) // 4 + 64, device=DEV)
+    assert lib.ovc_debug_clear_tuning() == 0        # "near" is relative to MEASURED entries: none from earlier tests of this process
     for chains in (1, 4, 104):
         assert lib.ovc_gemm_tuned_get(M, N, 1, K, chains, 1, 1, 0) == -1
         calls = lib.ovc_gemm_tune_calls()
@@ -564,6 +565,12 @@ def test_tuner_only_ranks_inside_the_class_and_borrows_neighbouring_shapes():
         assert lib.ovc_gemm_tuned_get(M + 40, N, 1, K, chains, 1, 1, 0) == -1     # exact look-up misses ...
         assert lib.ovc_gemm_tuned_get(M + 40, N, 1, K, chains, 1, 1, 1) == t      # ... the near one borrows the neighbour
         assert lib.ovc_gemm_tuned_get(4 * M, N, 1, K, chains, 1, 1, 1) == -1      # but not across more than a factor of two
+        # single-segment products also borrow along the COLUMN count with M equal (the transposed vocabulary product: its batch
+        # size is its seg_n) -- one axis at a time, within a factor of two
+        assert lib.ovc_gemm_tuned_get(M, N + 40, 1, K, chains, 1, 1, 0) == -1 and lib.ovc_gemm_tuned_get(M, N + 40, 1, K, chains, 1, 1, 1) == t
+        assert lib.ovc_gemm_tuned_get(M, N // 2, 1, K, chains, 1, 1, 1) == t and lib.ovc_gemm_tuned_get(M, 4 * N, 1, K, chains, 1, 1, 1) == -1
+        assert lib.ovc_gemm_tuned_get(M + 40, N + 40, 1, K, chains, 1, 1, 1) == -1
+        assert lib.ovc_gemm_tuned_get(M, 64, 3, K, chains, 1, 1, 1) == -1           # segmented products: M only
         # every objective has its own table, named in the call (ABI 6: no process-wide "current objective")
         assert lib.ovc_gemm_tuned_get(M, N, 1, K, chains, 1, 2, 1) == -1
         assert lib.ovc_gemm_tuned_set(M, N, 1, K, chains, 1, 2, t) == 0 and lib.ovc_gemm_tuned_get(M, N, 1, K, chains, 1, 2, 0) == t
