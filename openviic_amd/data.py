@@ -87,12 +87,22 @@ def collate_feature_fields(items: Sequence[dict]) -> dict:
 
 
 def feature_file_loader(paths: Sequence[str], batch_size: int, workers: int, keys: Optional[Iterable[str]] = None,
-                        trusted: bool = False, pin_memory: bool = True, prefetch_factor: int = 2, context=None):
+                        trusted: bool = False, pin_memory: bool = False, prefetch_factor: int = 2, context=None):
     """``DataLoader`` over feature files the way the reference feeds its loops (``trainers/base_trainer.py:40-80``: worker
     processes, ``collate_fn``): consecutive groups of ``batch_size`` paths, in order, each batch read and collated by ONE worker
     process and handed over through shared memory (a 105 MB batch at B = 256 is not pickled through a pipe: that is what
-    capped round 3's reader pool at 350 MB/s), then copied into pinned memory by the loader's pinning thread."""
+    capped round 3's reader pool at 350 MB/s).  ``pin_memory`` (the loader's own pinning thread) is OFF by default:
+    ``predict_feature_files`` copies into pinned buffers it allocates ONCE -- the pinning thread allocates and frees 105 MB of
+    pinned memory per batch, and every such allocation updates the GPU's page tables under the running decode (measured: the
+    decode of a batch then takes 183 ms instead of 11)."""
     from torch.utils.data import DataLoader
+    if workers > 0 and context == "forkserver":
+        # Workers are forked from a small server process that has torch and this module imported already: they come up in
+        # milliseconds (spawned interpreters import torch one after the other -- the parent blocks on each worker's start-up
+        # pipe -- 0.9 s per worker), and nothing is ever fork()ed from the caller's own (HIP-initialised) process.
+        import multiprocessing
+        context = multiprocessing.get_context("forkserver")
+        context.set_forkserver_preload(["torch", "numpy", __name__])
     return DataLoader(FeatureFileDataset(paths, keys, trusted), batch_size=batch_size, shuffle=False, num_workers=workers,
                       collate_fn=collate_feature_fields, pin_memory=pin_memory and workers > 0,
                       prefetch_factor=prefetch_factor if workers > 0 else None,
@@ -101,7 +111,7 @@ def feature_file_loader(paths: Sequence[str], batch_size: int, workers: int, key
 
 def predict_feature_files(model, vocab, paths: Sequence[str], batch_size: int, beam_size: int = 5, slots: int = 2,
                           keys: Optional[Iterable[str]] = None, trusted: bool = False, workers: int = 0,
-                          loader_context=None):
+                          loader_context="forkserver"):
     """The reference's prediction loop (``trainers/vi_trainer.py:241-252``: per batch ``items.to(device)`` ->
     ``model.beam_search(items, batch_size, beam_size, out_size=1)`` -> ``decode_caption`` -> duplicate collapse) as a
     software pipeline on ONE host thread:
@@ -123,14 +133,23 @@ def predict_feature_files(model, vocab, paths: Sequence[str], batch_size: int, b
 
     ``workers > 0`` (round 4): the host side of the loop -- parsing the feature files and collating a batch, Python work that
     one thread does at 600-880 images/s -- moves into ``workers`` ``DataLoader`` processes (``feature_file_loader``); batches
-    arrive already pinned and go straight to the copy stream.  Same strings, in the same order.  ``loader_context``: the
-    ``multiprocessing`` start method of the workers (``None`` = the platform default, fork; ``"spawn"`` starts clean
-    interpreters, a few seconds slower to come up).
+    come back through shared memory, a copier thread moves each into a ring of pinned buffers that live as long as the model,
+    and the launching thread only ever sees pinned tensors.  Same strings, in the same order.  ``loader_context``: the
+    ``multiprocessing`` start method of the workers.  The default is ``"forkserver"`` (workers forked from a small server
+    process that has torch imported: up in milliseconds; ``"spawn"`` works too, 0.9 s per worker), NOT the platform's fork:
+    while a fork()ed child of this HIP-initialised process is alive, every page the parent writes is
+    copied first (copy-on-write, GPU-mapped host memory included) and the launching thread takes 64 ms per batch instead of 12
+    (tools/loader_stall_probe.py; a pure-Python thread holding the GIL costs about as much -- the copier thread's Python work
+    is a few calls per batch).
     """
+    import sys
+    import time
+
     import torch
 
     from .vocab import captions_from_ids
 
+    trace = os.environ.get("OVC_PREDICT_TRACE", "0") != "0"        # per-batch phase times on stderr (tools/loader_probe.py)
     device = next(model.parameters()).device
     if device.type != "cuda":
         raise RuntimeError("predict_feature_files needs the model on a HIP device; there is no CPU path")
@@ -148,9 +167,11 @@ def predict_feature_files(model, vocab, paths: Sequence[str], batch_size: int, b
     def finish(slot):
         entry, pending[slot] = pending[slot], None
         if entry is not None:
-            names, ids_host, done, _host_batch = entry        # the host batch (pinned source of the async copy) lived until here
+            names, ids_host, done = entry
             done.synchronize()
             results.extend(zip(names, captions_from_ids(vocab, ids_host)))
+            if ring_of.get(slot) is not None:          # the batch's copy to the device is long done: its ring entry is free again
+                free_ring.put(ring_of.pop(slot))
 
     def pinned_like(slot, name, shape, dtype):
         numel = 1
@@ -161,26 +182,84 @@ def predict_feature_files(model, vocab, paths: Sequence[str], batch_size: int, b
             buf = pinned[slot][name] = torch.empty(max(numel, 1), dtype=dtype).pin_memory()
         return buf[:numel].view(tuple(shape))
 
+    ring_of = {}                                     # decode slot -> staging-ring entry of the batch in flight on it
+    free_ring = None
     if workers > 0:
-        source = iter(feature_file_loader(paths, batch_size, workers, keys=keys, trusted=trusted, context=loader_context))
+        # The host side in worker processes: a copier thread takes each collated batch out of the loader's shared memory and
+        # into a ring of pinned buffers that live as long as the model (one plain memcpy, GIL released), the launching thread
+        # only ever sees pinned tensors.  Ring entries return to the copier when their batch's strings have been built.
+        import queue
+        import threading
+        ring = state.setdefault("ring", [])
+        while len(ring) < slots + 2:
+            ring.append(dict())
+        free_ring, staged_q = queue.Queue(), queue.Queue(maxsize=len(ring))
+        for entry in range(len(ring)):
+            free_ring.put(entry)
+        loader = feature_file_loader(paths, batch_size, workers, keys=keys, trusted=trusted, context=loader_context)
+        failure = []
+
+        def stage_batches():
+            try:
+                it = iter(loader)
+                while True:
+                    t_a = time.perf_counter()
+                    try:
+                        fields = next(it)
+                    except StopIteration:
+                        break
+                    t_b = time.perf_counter()
+                    entry = free_ring.get()
+                    t_c = time.perf_counter()
+                    staged = InstanceList()
+                    for name, value in fields.items():
+                        if isinstance(value, torch.Tensor):
+                            numel = value.numel()
+                            buf = ring[entry].get(name)
+                            if buf is None or buf.numel() < numel or buf.dtype != value.dtype:
+                                buf = ring[entry][name] = torch.empty(max(numel, 1), dtype=value.dtype).pin_memory()
+                            stage = buf[:numel].view(value.shape)
+                            np.copyto(stage.numpy(), value.contiguous().numpy())
+                            staged[name] = stage
+                        else:
+                            staged[name] = value
+                    if trace:
+                        print("[predict] staging: loader %.1f ms, free entry %.1f ms, copy %.1f ms"
+                              % (1e3 * (t_b - t_a), 1e3 * (t_c - t_b), 1e3 * (time.perf_counter() - t_c)), file=sys.stderr, flush=True)
+                    staged_q.put((entry, staged))
+            except BaseException as error:            # surfaced in the launching thread
+                failure.append(error)
+            finally:
+                staged_q.put(None)
+        copier = threading.Thread(target=stage_batches, name="ovc-feature-staging", daemon=True)
+        copier.start()
+
+        def staged_source():
+            while True:
+                item = staged_q.get()
+                if item is None:
+                    if failure:
+                        raise failure[0]
+                    return
+                yield item
+        source = staged_source()
     else:
-        source = (batch_from_feature_files(paths[first:first + batch_size], keys=keys, trusted=trusted)
+        source = ((None, batch_from_feature_files(paths[first:first + batch_size], keys=keys, trusted=trusted))
                   for first in range(0, len(paths), batch_size))
     index = 0
+    t_prev = time.perf_counter()
     with torch.no_grad():
-        for host in source:
-            if not isinstance(host, InstanceList):
-                fields, host = host, InstanceList()
-                for name, value in fields.items():
-                    host[name] = value
+        for entry, host in source:
+            t_got = time.perf_counter()
             slot = index % slots
             index += 1
             finish(slot)                               # the slot's pinned buffers are free again once its last batch is done
+            t_fin = time.perf_counter()
             items = InstanceList()
             with torch.cuda.stream(copy_stream):
                 for name, value in host.items():
                     if isinstance(value, torch.Tensor):
-                        if value.is_pinned():          # from the loader's pinning thread: no staging copy (kept alive below)
+                        if entry is not None:          # already in the staging ring's pinned memory
                             stage = value
                         else:
                             stage = pinned_like(slot, name, value.shape, value.dtype)
@@ -199,7 +278,13 @@ def predict_feature_files(model, vocab, paths: Sequence[str], batch_size: int, b
                 ids_host.copy_(outs, non_blocking=True)
                 done = torch.cuda.Event()
                 done.record(decode_streams[slot])
-            pending[slot] = (list(host["filename"]) if "filename" in host else [None] * items.batch_size, ids_host, done, host)
+            pending[slot] = (list(host["filename"]) if "filename" in host else [None] * items.batch_size, ids_host, done)
+            ring_of[slot] = entry
+            if trace:
+                now = time.perf_counter()
+                print("[predict] batch %d: waited %.1f ms for it, finish(previous on slot) %.1f ms, launch %.1f ms"
+                      % (index - 1, 1e3 * (t_got - t_prev), 1e3 * (t_fin - t_got), 1e3 * (now - t_fin)), file=sys.stderr, flush=True)
+                t_prev = now
     for step in range(slots):                          # oldest first
         finish((index + step) % slots)
     return results

@@ -318,8 +318,8 @@ def test_pipelined_prediction_matches_the_sequential_loop(tmp_path):
             piped = predict_feature_files(model, vocab, paths, batch_size=batch_size, beam_size=want["beam_size"], slots=slots)
             assert piped == sequential, (batch_size, slots)
         # the host side in DataLoader worker processes (round 4): batches arrive through shared memory,
-        # already pinned -- same strings in the same order, with forked and with spawned workers
-        for context in (None, "spawn"):
+        # and are staged into a ring of pinned buffers -- same strings in the same order, whatever the workers' start method
+        for context in ("forkserver", "spawn", None):
             fed = predict_feature_files(model, vocab, paths, batch_size=batch_size, beam_size=want["beam_size"], slots=2,
                                         workers=2, loader_context=context)
             assert fed == sequential, (batch_size, context)
