@@ -111,7 +111,7 @@ def feature_file_loader(paths: Sequence[str], batch_size: int, workers: int, key
 
 def predict_feature_files(model, vocab, paths: Sequence[str], batch_size: int, beam_size: int = 5, slots: int = 2,
                           keys: Optional[Iterable[str]] = None, trusted: bool = False, workers: int = 0,
-                          loader_context="forkserver"):
+                          loader_context="forkserver", early_exit: bool = False):
     """The reference's prediction loop (``trainers/vi_trainer.py:241-252``: per batch ``items.to(device)`` ->
     ``model.beam_search(items, batch_size, beam_size, out_size=1)`` -> ``decode_caption`` -> duplicate collapse) as a
     software pipeline on ONE host thread:
@@ -141,6 +141,10 @@ def predict_feature_files(model, vocab, paths: Sequence[str], batch_size: int, b
     copied first (copy-on-write, GPU-mapped host memory included) and the launching thread takes 64 ms per batch instead of 12
     (tools/loader_stall_probe.py; a pure-Python thread holding the GIL costs about as much -- the copier thread's Python work
     is a few calls per batch).
+
+    ``early_exit=True``: decode with ``ovc_beam_search_early`` -- no step is issued once every beam of the batch has ended (real
+    captions end well before ``max_len``); same strings.  That call blocks the launching thread until its batch is one step
+    from done, so batches overlap less; with the host side in worker processes that costs little.
     """
     import sys
     import time
@@ -273,7 +277,8 @@ def predict_feature_files(model, vocab, paths: Sequence[str], batch_size: int, b
                 ready.record(copy_stream)
             with torch.cuda.stream(decode_streams[slot]):
                 decode_streams[slot].wait_event(ready)
-                outs, _ = model.beam_search(items, batch_size=items.batch_size, beam_size=beam_size, out_size=1)
+                outs, _ = model.beam_search(items, batch_size=items.batch_size, beam_size=beam_size, out_size=1,
+                                            early_exit=early_exit)
                 ids_host = pinned_like(slot, "__ids__", outs.shape, outs.dtype)
                 ids_host.copy_(outs, non_blocking=True)
                 done = torch.cuda.Event()

@@ -323,6 +323,8 @@ def test_pipelined_prediction_matches_the_sequential_loop(tmp_path):
             fed = predict_feature_files(model, vocab, paths, batch_size=batch_size, beam_size=want["beam_size"], slots=2,
                                         workers=2, loader_context=context)
             assert fed == sequential, (batch_size, context)
+        early = predict_feature_files(model, vocab, paths, batch_size=batch_size, beam_size=want["beam_size"], slots=2, early_exit=True)
+        assert early == sequential, batch_size
     assert [name for name, _ in sequential] == [os.path.basename(p) for p in paths]
 
 
