@@ -202,6 +202,7 @@ def predict_feature_files(model, vocab, paths: Sequence[str], batch_size: int, b
             free_ring.put(entry)
         loader = feature_file_loader(paths, batch_size, workers, keys=keys, trusted=trusted, context=loader_context)
         failure = []
+        stopping = threading.Event()                 # set when the launching thread leaves early (an exception): see `finally`
 
         def stage_batches():
             try:
@@ -214,6 +215,8 @@ def predict_feature_files(model, vocab, paths: Sequence[str], batch_size: int, b
                         break
                     t_b = time.perf_counter()
                     entry = free_ring.get()
+                    if stopping.is_set():
+                        break
                     t_c = time.perf_counter()
                     staged = InstanceList()
                     for name, value in fields.items():
@@ -234,7 +237,8 @@ def predict_feature_files(model, vocab, paths: Sequence[str], batch_size: int, b
             except BaseException as error:            # surfaced in the launching thread
                 failure.append(error)
             finally:
-                staged_q.put(None)
+                del it                                 # shuts the loader's worker processes down
+                staged_q.put(None)                     # never blocks: at most len(ring) - 1 batches are staged at a time
         copier = threading.Thread(target=stage_batches, name="ovc-feature-staging", daemon=True)
         copier.start()
 
@@ -252,44 +256,54 @@ def predict_feature_files(model, vocab, paths: Sequence[str], batch_size: int, b
                   for first in range(0, len(paths), batch_size))
     index = 0
     t_prev = time.perf_counter()
-    with torch.no_grad():
-        for entry, host in source:
-            t_got = time.perf_counter()
-            slot = index % slots
-            index += 1
-            finish(slot)                               # the slot's pinned buffers are free again once its last batch is done
-            t_fin = time.perf_counter()
-            items = InstanceList()
-            with torch.cuda.stream(copy_stream):
-                for name, value in host.items():
-                    if isinstance(value, torch.Tensor):
-                        if entry is not None:          # already in the staging ring's pinned memory
-                            stage = value
+    try:
+        with torch.no_grad():
+            for entry, host in source:
+                t_got = time.perf_counter()
+                slot = index % slots
+                index += 1
+                finish(slot)                               # the slot's pinned buffers are free again once its last batch is done
+                t_fin = time.perf_counter()
+                items = InstanceList()
+                with torch.cuda.stream(copy_stream):
+                    for name, value in host.items():
+                        if isinstance(value, torch.Tensor):
+                            if entry is not None:          # already in the staging ring's pinned memory
+                                stage = value
+                            else:
+                                stage = pinned_like(slot, name, value.shape, value.dtype)
+                                stage.copy_(value)
+                            dev = stage.to(device, non_blocking=True)
+                            dev.record_stream(decode_streams[slot])
+                            items[name] = dev
                         else:
-                            stage = pinned_like(slot, name, value.shape, value.dtype)
-                            stage.copy_(value)
-                        dev = stage.to(device, non_blocking=True)
-                        dev.record_stream(decode_streams[slot])
-                        items[name] = dev
-                    else:
-                        items[name] = value
-                ready = torch.cuda.Event()
-                ready.record(copy_stream)
-            with torch.cuda.stream(decode_streams[slot]):
-                decode_streams[slot].wait_event(ready)
-                outs, _ = model.beam_search(items, batch_size=items.batch_size, beam_size=beam_size, out_size=1,
-                                            early_exit=early_exit)
-                ids_host = pinned_like(slot, "__ids__", outs.shape, outs.dtype)
-                ids_host.copy_(outs, non_blocking=True)
-                done = torch.cuda.Event()
-                done.record(decode_streams[slot])
-            pending[slot] = (list(host["filename"]) if "filename" in host else [None] * items.batch_size, ids_host, done)
-            ring_of[slot] = entry
-            if trace:
-                now = time.perf_counter()
-                print("[predict] batch %d: waited %.1f ms for it, finish(previous on slot) %.1f ms, launch %.1f ms"
-                      % (index - 1, 1e3 * (t_got - t_prev), 1e3 * (t_fin - t_got), 1e3 * (now - t_fin)), file=sys.stderr, flush=True)
-                t_prev = now
-    for step in range(slots):                          # oldest first
-        finish((index + step) % slots)
+                            items[name] = value
+                    ready = torch.cuda.Event()
+                    ready.record(copy_stream)
+                with torch.cuda.stream(decode_streams[slot]):
+                    decode_streams[slot].wait_event(ready)
+                    outs, _ = model.beam_search(items, batch_size=items.batch_size, beam_size=beam_size, out_size=1,
+                                                early_exit=early_exit)
+                    ids_host = pinned_like(slot, "__ids__", outs.shape, outs.dtype)
+                    ids_host.copy_(outs, non_blocking=True)
+                    done = torch.cuda.Event()
+                    done.record(decode_streams[slot])
+                pending[slot] = (list(host["filename"]) if "filename" in host else [None] * items.batch_size, ids_host, done)
+                ring_of[slot] = entry
+                if trace:
+                    now = time.perf_counter()
+                    print("[predict] batch %d: waited %.1f ms for it, finish(previous on slot) %.1f ms, launch %.1f ms"
+                          % (index - 1, 1e3 * (t_got - t_prev), 1e3 * (t_fin - t_got), 1e3 * (now - t_fin)), file=sys.stderr, flush=True)
+                    t_prev = now
+        for step in range(slots):                      # oldest first
+            finish((index + step) % slots)
+    finally:
+        if workers > 0:                                # leaving early (an exception above): let the copier thread and its loader go
+            stopping.set()
+            free_ring.put(0)
+            while copier.is_alive():
+                try:
+                    staged_q.get(timeout=0.05)
+                except queue.Empty:
+                    pass
     return results

@@ -886,15 +886,17 @@ def test_early_exit_on_the_forced_eos_fixtures(variant):
         assert steps <= last[b] + 3 < T + 1, (b, steps, last[b])        # noticed one step late, one more step already queued
 
 
-def test_early_exit_on_captions_of_realistic_length():
+@pytest.mark.parametrize("B,V", [(48, 300), (12, 16500)])
+def test_early_exit_on_captions_of_realistic_length(B, V):
     """Synthetic weights whose <eos> logit rises with the position (utils/synthetic.py::eos_biased_state_dict): every beam ends
     between steps ~6 and ~12 of 20.  Oracle parity first (the biased weights are an ordinary model), then early exit == full run
-    bit for bit at B = 48, beam 5, with a third of the steps never issued; B = 1 as well."""
+    bit for bit at B = 48, beam 5, with a third of the steps never issued; B = 1 as well.  V = 16 500 takes the two-kernel
+    selection (more than 512 blocks of 32 words), whose update kernel counts the live beams too."""
     from openviic_amd.builders import build_model
     from openviic_amd.config import model_config
     from openviic_amd.utils.synthetic import SyntheticVocab, eos_biased_state_dict, synthetic_features, synthetic_state_dict
     dims = dict(d_feature=64, d_model=128, heads=2, d_kv=64, d_ff=256, layers=2)
-    B, N, V, T, k = 48, 20, 300, 20, 5
+    N, T, k = 20, 20, 5
     vocab = SyntheticVocab(V, T)
     cfg = model_config("standard_transformer", device="cpu", **dims)
     template = build_model(cfg, vocab).state_dict()
