@@ -3,7 +3,7 @@
 
 For every (shape, K-order class, K split) the engine issues: time of each tiling of that class
 (ovc_debug_linear_tiling, back-to-back launches issued from C) and of torch.addmm (rocBLAS / hipBLASLt) as a
-same-hardware reference.  Random operands.   python tools/gemm_bench.py [decode|encoder|all] [split]
+same-hardware reference.  Random operands.   python tools/gemm_bench.py [decode|encoder|small|all] [split]
 With "split": also the opt-in split-precision classes (bf16 planes, gemm_split.h) with their error against an fp64 product.
 """
 import sys, os
@@ -16,6 +16,10 @@ DECODE = [  # (M, N, K, kchains, ksplit, note)
     (1280, 2048, 512, 4, 1, "dec ffn1"), (1280, 512, 2048, 4, 4, "dec ffn2 /4"), (1280, 512, 2048, 4, 2, "dec ffn2 /2"), (1280, 512, 2048, 4, 1, "dec ffn2 /1"),
     (1280, 10201, 512, 4, 1, "vocab"), (256, 512, 512, 4, 1, "t=0 proj"), (256, 10201, 512, 4, 1, "t=0 vocab"),
 ]
+# the reference's own operating points (B = 1 and B = 8 at beam 5: 5 and 40 decode rows; base_trainer.py:75-80)
+SMALL = [(rows, n, k, 4, ks, "%s rows=%d" % (name, rows)) for rows in (5, 40)
+         for n, k, ks, name in ((512, 512, 1, "cross-q"), (512, 512, 2, "o-proj /2"), (1536, 512, 1, "qkv"), (2048, 512, 1, "ffn1"),
+                                (512, 2048, 4, "ffn2 /4"))]
 ENCODER = [
     (12800, 512, 2048, 1, 1, "feature proj"), (12800, 1536, 512, 1, 1, "enc qkv"), (12800, 512, 512, 1, 1, "enc o"),
     (12800, 2048, 512, 1, 1, "enc ffn1"), (12800, 3072, 512, 1, 1, "cross kv"),
@@ -70,7 +74,8 @@ def main():
     which = sys.argv[1] if len(sys.argv) > 1 else "all"
     split = "split" in sys.argv[2:]
     lib = native.load()
-    shapes = (DECODE if which in ("decode", "all") else []) + (ENCODER if which in ("encoder", "all") else [])
+    shapes = ((DECODE if which in ("decode", "all") else []) + (ENCODER if which in ("encoder", "all") else []) +
+              (SMALL if which == "small" else []))
     tl = tilings(lib)
     for M, N, K, chains, ksplit, note in shapes:
         x = torch.randn(M, K, device="cuda")
