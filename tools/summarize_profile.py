@@ -10,7 +10,7 @@ import collections, csv, glob, json, os, shutil, sys
 tag = sys.argv[1]
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gpurun_out", tag)
-dst = os.path.join(root, "profiles")
+dst = os.environ.get("OVC_PROFILE_DST") or os.path.join(root, "profiles")     # on the GPU box: a directory under gpurun_out/
 os.makedirs(dst, exist_ok=True)
 
 
