@@ -81,7 +81,7 @@ int ovc_layer_norm(const float* x, const float* residual, const float* gamma, co
  *   queries), NULL = no mask.  Memory slots (mem_k [m,h*dk], mem_v [m,h*dv], may be NULL):
  *   m extra keys mem_scale_k*mem_k and values mem_scale_v*mem_v appended after the nk real
  *   keys and never masked.  dk, dv multiples of 4 and <= 64; any nq, nk, m (the reference has no limit either:
- *   attentions.py:44-58): up to 128 keys (nk + m) and 128 queries the scores of a query stay in registers; beyond that the
+ *   attentions.py:44-58): up to 192 keys (nk + m) and 128 queries the scores of a query stay in registers; beyond that the
  *   keys pass in tiles of 128, ascending, under an online softmax (a fixed order: results depend on the operands only).
  *   A query whose keys are all masked gets NaN, as torch.softmax over a row of -inf does.
  * Replaces attentions.py:51-55 (plain), :102-111 (geometry), :171-183 (memory). */
@@ -205,9 +205,9 @@ typedef struct {
 
 /* Sizes the engine accepts (anything else: ovc_workspace_bytes returns 0, the calls OVC_EINVAL) -- the
  * reference itself has no such limits, these are the template instances built so far:
- *   regions N <= OVC_MAX_REGIONS (1024), memory slots on top of them without a limit of their own (N + memory <= 128
- *   runs on the register-resident attention instances, anything larger on the key-tiled ones -- e.g. the shipped
- *   meshed_memory_transformer.yaml, MEMORY: 40, with 89..1024 regions);  beam k <= OVC_MAX_BEAM (8);  max_len <= 64;  any vocabulary (above 16384 words the
+ *   regions N <= OVC_MAX_REGIONS (1024), memory slots on top of them without a limit of their own (N <= 128 with
+ *   N + memory <= 192 runs on the register-resident attention instances -- the shipped meshed_memory_transformer.yaml,
+ *   MEMORY: 40, for every N <= 128 -- anything larger on the key-tiled ones);  beam k <= OVC_MAX_BEAM (8);  max_len <= 64;  any vocabulary (above 16384 words the
  *   selection streams each row k + 2 times instead of holding it in registers);
  *   d_model <= 2048 (multiple of 4; of 32 for models with AoA gates or the meshed decoder, whose products over a
  *   concatenated input read the two halves from their own buffers);  d_k == d_v in {4, 8, 16, 32, 64}, heads <= 32,

@@ -177,7 +177,7 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(AttnArgs p) {
 //       over the two keys base_r and base_r + 4 that the two lane halves hold in register r; the A operand
 //       V[key][dv = lane & 31] is a conflict-free 128-byte ds_read_b32 per half.
 //   The output tile goes through LDS once (the K image is free by then) so that rows leave as whole 256-byte lines.
-// NKT = key tiles of 32 (real keys + memory slots, <= 4); KG = 8-deep d groups of Q.K (dk <= 8 KG);
+// NKT = key tiles of 32 (real keys + memory slots, <= 6); KG = 8-deep d groups of Q.K (dk <= 8 KG);
 // DVT = 32-wide tiles of d_v.  Numerics: scores and probabilities as in the general kernel (same scale, mask,
 // geometry order, expf, division); only the order of the softmax sum and of the P.V sum over keys differs.
 // -------------------------------------------------------------------------------------------------
@@ -335,7 +335,8 @@ __global__ __launch_bounds__(256) void attention_regs_kernel(AttnArgs p) {
 }
 
 // -------------------------------------------------------------------------------------------------
-// attention_tiled_kernel: the same operator without a limit on the number of keys or queries (round 4).  The reference has
+// attention_tiled_kernel: the same operator without a limit on the number of keys or queries (round 4; shapes beyond the
+// register instances: more than 192 keys, or more than 128 keys for more than 128 queries).  The reference has
 // none (attentions.py:44-58 works on any nk, :158-185 appends its 40 memory slots to any nk): bottom-up feature sets carry up
 // to 100 regions per image (+ 40 slots = 140 keys), grid features 14 x 14 = 196 cells, the DLCT form regions + cells.
 //
@@ -346,8 +347,8 @@ __global__ __launch_bounds__(256) void attention_regs_kernel(AttnArgs p) {
 // per-lane scalar here because a lane's accumulator registers all belong to ITS query.  The tile order is fixed, so a result
 // depends on nothing but the operands (no timing, no batch size).  Fully masked rows end with L = 0 and give 0 / 0 = NaN,
 // as the reference's softmax over a row of -inf does.  Numerics vs the kernels above: the division by the softmax sum
-// happens once at the end instead of per probability (~1 ulp per output); shapes with nk + m <= 128 and nq <= 128 never come
-// here, so nothing that ran before round 4 changes a bit.
+// happens once at the end instead of per probability (~1 ulp per output); shapes with nk + m <= 192 and nq <= 128 never come
+// here (they have register instances), so nothing that ran before round 4 changes a bit.
 // KG = 8-deep d groups of Q.K (dk <= 8 KG); DVT = 32-wide tiles of d_v.
 // -------------------------------------------------------------------------------------------------
 template <int KG, int DVT>
@@ -532,7 +533,9 @@ extern "C" int ovc_attention(const float* q, const float* k, const float* v, int
     // the accumulators.  Head sizes up to 64, key tiles up to 4 x 32: everything the path uses.
     {
         const int nkt = (nk + m + 31) / 32, waves = (nq + 31) / 32, hmax = dk > dv ? dk : dv;
-        if (nkt <= 4 && waves <= 4 && !OVC_HOOK_ENV("OVC_ATTENTION_GENERAL")) {
+        // up to 192 keys (six 32-key tiles: 128 regions + 40 memory slots and a bit) for up to 128 queries; instances 5 and 6 exist
+        // since round 4 so that the shipped meshed-memory configuration (MEMORY: 40) stays on this kernel for every N <= 128
+        if (nkt <= 6 && waves <= 4 && !OVC_HOOK_ENV("OVC_ATTENTION_GENERAL")) {
             const int k_rows = nkt * 32 > waves * 32 ? nkt * 32 : waves * 32;
             const size_t bytes = sizeof(float) * (size_t)(k_rows + nkt * 32) * kLdQK;
             const dim3 grid(b * h), block(256);
@@ -541,7 +544,7 @@ extern "C" int ovc_attention(const float* q, const float* k, const float* v, int
         static std::once_flag once;                                                                                   \
         std::call_once(once, [] {                                                                                     \
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attention_regs_kernel<NKT, KG, DVT>),            \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);                         \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 112 * 1024);                        \
         });                                                                                                           \
         hipLaunchKernelGGL((attention_regs_kernel<NKT, KG, DVT>), grid, block, bytes, ovc_hip_stream(stream), p);     \
     } while (0)
@@ -549,14 +552,16 @@ extern "C" int ovc_attention(const float* q, const float* k, const float* v, int
     do {                                                                                                              \
         if (hmax <= 16) OVC_ATT(NKT, 2, 1); else if (hmax <= 32) OVC_ATT(NKT, 4, 1); else OVC_ATT(NKT, 8, 2);          \
     } while (0)
-            if (nkt == 1) OVC_ATT_H(1); else if (nkt == 2) OVC_ATT_H(2); else if (nkt == 3) OVC_ATT_H(3); else OVC_ATT_H(4);
+            if (nkt == 1) OVC_ATT_H(1); else if (nkt == 2) OVC_ATT_H(2); else if (nkt == 3) OVC_ATT_H(3); else if (nkt == 4) OVC_ATT_H(4);
+            else if (nkt == 5) OVC_ATT_H(5); else OVC_ATT_H(6);
 #undef OVC_ATT_H
 #undef OVC_ATT
             OVC_RETURN_IF_LAUNCH_FAILED();
             return OVC_OK;
         }
     }
-    // More than 128 keys (real + memory slots): the key-tiled kernel with an online softmax, any nq and nk.
+    // More than 192 keys (real + memory slots), or more than 128 keys for more than 128 queries: the key-tiled kernel with an
+    // online softmax, any nq and nk.
     if (nk + m > 128) {
         const int hmax = dk > dv ? dk : dv;
         p.qtiles = (nq + 127) / 128;

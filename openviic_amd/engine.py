@@ -329,11 +329,12 @@ class CaptionEngine:
         target = -(-N // bucket) * bucket
         if target > native.OVC_MAX_REGIONS:   # the bucket would pass the engine's region limit: keep the exact shape (an N beyond
             target = N                        # the limit then reaches ovc_workspace_bytes and raises -- padding never crops)
-        # Up to 128 keys (regions + the encoder's memory slots) the attention kernels keep a query's scores in registers, beyond
-        # that the keys pass in tiles under an online softmax (csrc/attention.hip): the two forms round differently, so a
-        # bucket never carries a batch across that edge -- the padded decode stays bit-identical to the unpadded one.
+        # Up to 128 regions (and 192 keys: regions + the encoder's memory slots) the attention kernels keep a query's scores in
+        # registers, beyond that the keys pass in tiles under an online softmax (csrc/attention.hip): the two forms round
+        # differently, so a bucket never carries a batch across that edge -- the padded decode stays bit-identical to the
+        # unpadded one.
         memory = int(getattr(getattr(self, "desc", None), "memory", 0) or 0)
-        for edge in sorted({max(128 - memory, 0), 128}):
+        for edge in sorted({max(192 - memory, 0), 128}):
             if N <= edge < target:
                 target = edge
                 break

@@ -318,13 +318,13 @@ def test_region_bucket_pads_and_never_crops():
         region_bucket = 1
     class Desc:
         memory = 0
-    # (bucket, N, padded N, memory slots): a bucket never carries a batch across 128 keys, where the attention kernels change
-    # from the register-resident to the key-tiled form (different rounding: the padded decode would no longer be bit-identical)
+    # (bucket, N, padded N, memory slots): a bucket never carries a batch across 128 regions / 192 keys, where the attention kernels
+    # change from the register-resident to the key-tiled form (different rounding: the padded decode would no longer be bit-identical)
     for bucket, n, want, memory in ((1, 130, 130, 0), (16, 129, 144, 0), (16, 130, 144, 0), (16, 120, 128, 0), (16, 113, 128, 0),
                                     (8, 37, 40, 0), (16, 128, 128, 0), (1, 50, 50, 0), (16, 127, 128, 0), (16, 1020, 1024, 0),
                                     (16, 1024, 1024, 0), (16, 1025, 1025, 0), (1, 1030, 1030, 0), (64, 1000, 1024, 0),
-                                    (48, 1010, 1010, 0), (48, 120, 128, 0), (16, 85, 88, 40), (16, 88, 88, 40), (16, 89, 96, 40),
-                                    (16, 50, 64, 40), (48, 100, 128, 40), (16, 130, 144, 40)):
+                                    (48, 1010, 1010, 0), (48, 120, 128, 0), (16, 85, 96, 40), (16, 120, 128, 40), (48, 100, 128, 40),
+                                    (16, 50, 64, 40), (16, 130, 144, 40), (16, 85, 92, 100), (16, 92, 92, 100), (16, 93, 96, 100)):
         Stub.region_bucket = bucket
         Desc.memory = memory
         Stub.desc = Desc

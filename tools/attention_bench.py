@@ -35,7 +35,7 @@ def main():
         torch.cuda.synchronize()
         us = e0.elapsed_time(e1) / 20 * 1e3
         flops = 4.0 * b * h * nq * (nk + m) * dk
-        kind = "registers" if nk + m <= 128 and nq <= 128 else ("key tiles" if nk + m > 128 else "LDS scores")
+        kind = "registers" if nk + m <= 192 and nq <= 128 else ("key tiles" if nk + m > 128 else "LDS scores")
         print("%4d %4d %4d  %-10s %10.1f %12.1f %14.3f" % (nq, nk, m, kind, us, flops / us / 1e6, us / (b * h * nq * (nk + m) / 1e3)))
 
 
