@@ -36,7 +36,7 @@ def _draw(rng):
         dims["d_model"] = 32 * rng.randint(1, 8)                         # two-block products: d_model a multiple of 32 (else refused)
     if variant == "meshed_memory_transformer":
         dims["memory"] = rng.choice([1, 3, 8, 17, 40])
-    # region counts on both sides of the 128-key edge (regions + memory slots) between the register-resident and the key-tiled
+    # region counts on both sides of the edge (128 regions / 192 keys with the memory slots) between the register-resident and the key-tiled
     # attention instances; round 3's draw stopped at 65 and could not see that 89..128 regions + 40 slots failed late
     B, N = rng.randint(1, 7), rng.choice([1, 2, 3, 5, 8, 13, 16, 17, 31, 32, 33, 50, 64, 65, 88, 89, 100, 127, 128, 129, 150, 196, 257])
     V = rng.choice([5, 9, 33, 64, 100, 257, 1000, 4099])
@@ -178,7 +178,7 @@ def test_random_call_sequences_replay_graphs_like_plain_launches():
 
 def test_random_dual_collaborative_encoders_against_the_oracle():
     """the dual-collaborative (DLCT) embedding + encoder on random sizes -- region counts, grid sizes
-    (n + g*g keys up to 244: both sides of the 128-key edge of the attention instances), feature widths, head shapes, layers, both box embeddings -- against ``oracle/dlct.py``: the five
+    (n + g*g keys up to 244: both sides of the register / key-tiled edge of the attention instances), feature widths, head shapes, layers, both box embeddings -- against ``oracle/dlct.py``: the five
     masks bit-exact, the encoder output by its relative L2 error (its geometry bias is the object-relation one, see above)."""
     from helpers import dlct_case
     from openviic_amd.builders import build_encoder, build_vision_embedding
