@@ -744,15 +744,51 @@ void destroy_entry(GraphEntry& g) {       // caller holds g_graph_mutex
     g.exec = nullptr; g.graph = nullptr;
 }
 
-void evict_lru(const GraphKey& keep) {     // caller holds g_graph_mutex
-    while (g_graphs.size() > graph_cache_capacity()) {
+// The per-step graphs of ovc_beam_search_early (one entry = max_len + 1 graphs, pinned memory and events); declared here
+// because the two caches share ONE bound.
+struct EarlyEntry {
+    int calls = 0;
+    bool unsupported = false;
+    hipGraph_t prologue_graph = nullptr; hipGraphExec_t prologue_exec = nullptr;
+    std::vector<hipGraph_t> step_graph; std::vector<hipGraphExec_t> step_exec;
+    std::vector<hipEvent_t> step_done;
+    int32_t* host_alive = nullptr;                 // pinned [T]
+    hipStream_t last_stream = nullptr;
+    uint64_t last_use = 0;
+    std::mutex in_use;                             // one search at a time per (model, shape, workspace)
+    ~EarlyEntry() {
+        if (last_stream) (void)hipStreamSynchronize(last_stream);
+        for (hipGraphExec_t x : step_exec) if (x) (void)hipGraphExecDestroy(x);
+        for (hipGraph_t g : step_graph) if (g) (void)hipGraphDestroy(g);
+        if (prologue_exec) (void)hipGraphExecDestroy(prologue_exec);
+        if (prologue_graph) (void)hipGraphDestroy(prologue_graph);
+        for (hipEvent_t ev : step_done) if (ev) (void)hipEventDestroy(ev);
+        if (host_alive) (void)hipHostFree(host_alive);
+    }
+};
+std::map<GraphKey, std::shared_ptr<EarlyEntry>> g_early;        // guarded by g_graph_mutex
+
+// Least-recently-used eviction over BOTH caches: together they hold at most OVC_GRAPH_CACHE_MAX entries.  `keep` / `keep_early`
+// (the entry the caller is about to use) are never evicted; an early-exit entry that another thread is still using lives on in
+// that thread's shared_ptr.  Caller holds g_graph_mutex.
+void evict_lru(const GraphKey* keep, const EarlyEntry* keep_early) {
+    while (g_graphs.size() + g_early.size() > graph_cache_capacity()) {
         auto victim = g_graphs.end();
         for (auto it = g_graphs.begin(); it != g_graphs.end(); ++it)
-            if (!(!(it->first < keep) && !(keep < it->first)) && (victim == g_graphs.end() || it->second.last_use < victim->second.last_use))
+            if (!(keep && !(it->first < *keep) && !(*keep < it->first)) && (victim == g_graphs.end() || it->second.last_use < victim->second.last_use))
                 victim = it;
-        if (victim == g_graphs.end()) return;
-        destroy_entry(victim->second);
-        g_graphs.erase(victim);
+        auto victim_early = g_early.end();
+        for (auto it = g_early.begin(); it != g_early.end(); ++it)
+            if (it->second.get() != keep_early && (victim_early == g_early.end() || it->second->last_use < victim_early->second->last_use))
+                victim_early = it;
+        const bool have = victim != g_graphs.end(), have_early = victim_early != g_early.end();
+        if (!have && !have_early) return;
+        if (have_early && (!have || victim_early->second->last_use < victim->second.last_use)) {
+            g_early.erase(victim_early);
+        } else {
+            destroy_entry(victim->second);
+            g_graphs.erase(victim);
+        }
     }
 }
 
@@ -809,7 +845,7 @@ extern "C" int ovc_beam_search_graph(const ovc_model* m, const float* features, 
     entry.calls += 1;
     entry.last_use = ++g_graph_tick;
     entry.last_stream = e.stream;
-    evict_lru(key);
+    evict_lru(&key, nullptr);
 
     TRY(run_encoder_inputs(e, w, features, boxes, B, N));
     // The launch sequence is captured on a PRIVATE stream, never on the caller's: while a stream is capturing, HIP
@@ -858,27 +894,6 @@ extern "C" int ovc_beam_search_graph(const ovc_model* m, const float* features, 
 // below -999 (a frozen beam's other candidates, beam_search.py:54).
 // ---------------------------------------------------------------------------------------------
 namespace {
-struct EarlyEntry {
-    int calls = 0;
-    bool unsupported = false;
-    hipGraph_t prologue_graph = nullptr; hipGraphExec_t prologue_exec = nullptr;
-    std::vector<hipGraph_t> step_graph; std::vector<hipGraphExec_t> step_exec;
-    std::vector<hipEvent_t> step_done;
-    int32_t* host_alive = nullptr;                 // pinned [T]
-    hipStream_t last_stream = nullptr;
-    uint64_t last_use = 0;
-    std::mutex in_use;                             // one search at a time per (model, shape, workspace)
-    ~EarlyEntry() {
-        if (last_stream) (void)hipStreamSynchronize(last_stream);
-        for (hipGraphExec_t x : step_exec) if (x) (void)hipGraphExecDestroy(x);
-        for (hipGraph_t g : step_graph) if (g) (void)hipGraphDestroy(g);
-        if (prologue_exec) (void)hipGraphExecDestroy(prologue_exec);
-        if (prologue_graph) (void)hipGraphDestroy(prologue_graph);
-        for (hipEvent_t ev : step_done) if (ev) (void)hipEventDestroy(ev);
-        if (host_alive) (void)hipHostFree(host_alive);
-    }
-};
-std::map<GraphKey, std::shared_ptr<EarlyEntry>> g_early;        // guarded by g_graph_mutex
 
 int issue_early_prologue(Engine& e, Workspace& w, int B, int N, int k) {
     const int R = B * k;
@@ -929,13 +944,7 @@ extern "C" int ovc_beam_search_early(const ovc_model* m, const float* features, 
         if (!slot) slot = std::make_shared<EarlyEntry>();
         entry = slot;
         entry->last_use = ++g_graph_tick;
-        while (g_early.size() > graph_cache_capacity()) {          // least recently used first; an entry in use lives on in its caller
-            auto victim = g_early.end();
-            for (auto it = g_early.begin(); it != g_early.end(); ++it)
-                if (it->second != entry && (victim == g_early.end() || it->second->last_use < victim->second->last_use)) victim = it;
-            if (victim == g_early.end()) break;
-            g_early.erase(victim);
-        }
+        evict_lru(nullptr, entry.get());                           // one bound for both caches, least recently used first
     }
     std::lock_guard<std::mutex> busy(entry->in_use);
     entry->calls += 1;
