@@ -919,6 +919,46 @@ def test_early_exit_on_captions_of_realistic_length(B, V):
     assert one <= steps
 
 
+def test_early_exit_from_two_host_threads():
+    """ovc_beam_search_early blocks its calling thread (it waits for each step's live-beam count), so hosts that overlap batches
+    drive one stream per thread: two threads, two streams, their own workspaces and per-step graphs, captures interleaving inside
+    the library -- every result equal to the single-threaded full run."""
+    import threading
+    from openviic_amd.builders import build_model
+    from openviic_amd.config import model_config
+    from openviic_amd.utils.synthetic import SyntheticVocab, eos_biased_state_dict, synthetic_features, synthetic_state_dict
+    dims = dict(d_feature=64, d_model=128, heads=2, d_kv=64, d_ff=256, layers=2)
+    V, T, k = 300, 20, 5
+    vocab = SyntheticVocab(V, T)
+    cfg = model_config("standard_transformer", device="cpu", **dims)
+    template = build_model(cfg, vocab).state_dict()
+    sd = eos_biased_state_dict(synthetic_state_dict(template, seed=5, mode="generic"), template)
+    model = device_model(cfg, vocab, sd)
+    parts = [synthetic_features(12, 20, 64, seed=31, ragged=True).cuda(), synthetic_features(7, 33, 64, seed=32, ragged=True).cuda()]
+    with torch.no_grad():
+        want = [model.beam_search(batch(p), batch_size=p.shape[0], beam_size=k) for p in parts]
+    torch.cuda.synchronize()
+    got, errors = [None, None], []
+
+    def work(i):
+        try:
+            s = torch.cuda.Stream()
+            with torch.no_grad(), torch.cuda.stream(s):
+                for _ in range(5):
+                    got[i] = model.beam_search(batch(parts[i]), batch_size=parts[i].shape[0], beam_size=k, early_exit=True)
+            s.synchronize()
+        except Exception as exc:            # pragma: no cover
+            errors.append(exc)
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors
+    for (ids, lp), (wi, wl) in zip(got, want):
+        assert torch.equal(ids, wi) and torch.equal(lp, wl)
+
+
 def test_grid_feature_architecture_reads_grid_features():
     """``StandardTransformerUsingGrid`` (standard_stransformer.py:45-68) is the region model fed from
     ``grid_features``: same weights + same tensor under the other field name -> same captions."""
