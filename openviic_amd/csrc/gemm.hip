@@ -123,15 +123,54 @@ __device__ __forceinline__ void tile_coords(int tiles_m, int group_m, int xcd_pm
     }
 }
 
+// The same map with every quotient precomputed on the host (round 4).  The kernel above spends 11 integer divisions (20
+// instructions and a dependent v_rcp each) and five DEPENDENT rounds of scalar loads -- kernel arguments, the dispatch packet
+// for gridDim, the dynamically indexed segment table -- before its first operand load is issued: 415 instructions and ~2 us of
+// an M = 1280 product's ~11.  Here the launch hands over a TileMap (divisors with their multiply-high magics, gridDim, the K
+// slice length) as the FIRST kernel argument, and the kernel fetches it together with every GemmArgs field the first tile's loads
+// need in ONE scalar round trip.  magic = floor(2^32 / d) + 1: mulhi(x, magic) == x / d for x * d < 2^32 (tile counts: always).
+struct TileMap {
+    int nwg, tiles_m, tiles_n_all, tiles_n_per_seg;
+    int xcd_pm, pm_shift, sub_m, sub_n;
+    unsigned sub_m_magic, seg_magic;
+    int group_m, group_size, gm_last;
+    unsigned group_size_magic, group_m_magic, gm_last_magic;
+    int kslice;
+};
+
+__device__ __forceinline__ int fast_div(int x, unsigned magic, int d) { return d == 1 ? x : (int)__umulhi((unsigned)x, magic); }
+
+__device__ __forceinline__ void tile_coords_fast(const TileMap& t, int bid, int& tile_m, int& tile_n_all) {
+    const int xcd = bid & 7, q = t.nwg >> 3, r = t.nwg & 7;
+    if (t.xcd_pm > 0) {
+        // 2-D split: nwg is a multiple of 8 here (tile_order), so the XCD's chunk is xcd itself and j = bid >> 3
+        const int j = bid >> 3;
+        const int cm = xcd & (t.xcd_pm - 1), cn = xcd >> t.pm_shift;
+        const int jq = fast_div(j, t.sub_m_magic, t.sub_m);
+        tile_m = cm * t.sub_m + (j - jq * t.sub_m);
+        tile_n_all = cn * t.sub_n + jq;
+    } else {
+        const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+        const int tile = base + (bid >> 3);
+        const int group = fast_div(tile, t.group_size_magic, t.group_size);
+        const int first_m = group * t.group_m;
+        const int in_group = tile - group * t.group_size;
+        const bool last = first_m + t.group_m > t.tiles_m;              // the partial last super-row
+        const int gm = last ? t.gm_last : t.group_m;
+        tile_n_all = last ? fast_div(in_group, t.gm_last_magic, t.gm_last) : fast_div(in_group, t.group_m_magic, t.group_m);
+        tile_m = first_m + (in_group - tile_n_all * gm);
+    }
+}
+
 // Epilogue of a wave's TM x TN accumulator tiles: + bias, activation, + residual, store (or, K-split, the raw partial product
 // of slice blockIdx.y).  D layout of a 32x32 tile: col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).  Branch-free on buffer
 // descriptors: one per-lane byte offset (first row of the lane's 16, its column) and a scalar row offset per accumulator
 // register; rows past M fall outside the descriptor and are dropped by the hardware, columns past seg_n get an
 // out-of-range offset.  (m0, n0) = first row / column of the wave's tiles.
 template <int TM, int TN>
-__device__ __forceinline__ void store_wave_tiles(const GemmArgs& p, int seg, const f32x16 (&acc)[TM][TN], int m0, int n0, int lane) {
-    const float* __restrict__ bias = p.seg[seg].bias;
-    float* __restrict__ C = p.seg[seg].C + (size_t)blockIdx.y * p.part_stride;
+__device__ __forceinline__ void store_wave_tiles(const GemmArgs& p, const float* __restrict__ bias, float* __restrict__ Cseg,
+                                                 const f32x16 (&acc)[TM][TN], int m0, int n0, int lane) {
+    float* __restrict__ C = Cseg + (size_t)blockIdx.y * p.part_stride;
     const int half = lane >> 5;
     const bool has_res = p.R != nullptr;                          // uniform
     const __amdgpu_buffer_rsrc_t rsrc_c = __builtin_amdgcn_make_buffer_rsrc(C, 0, p.M * p.ldc * 4, 0x00020000);
@@ -229,7 +268,7 @@ template <int BM, int BN, int BK, int NC>
 constexpr int min_waves_per_simd() { return BM * BN <= 32 * 64 ? 5 : (BM * BN <= 64 * 64 ? (NC == 4 && BK == 64 ? 3 : 4) : 1); }
 
 template <int BM, int BN, int WM, int WN, int WK, int BK, int NC>
-__global__ __launch_bounds__(256, (min_waves_per_simd<BM, BN, BK, NC>())) void gemm_f32_mfma(GemmArgs p, int tiles_m, int tiles_n_per_seg, int group_m, int xcd_pm) {
+__global__ __launch_bounds__(256, (min_waves_per_simd<BM, BN, BK, NC>())) void gemm_f32_mfma(TileMap tmap, GemmArgs p) {
     using Cfg = TileConfig<BM, BN, WM, WN, WK, BK, NC>;
     constexpr int LDT = Cfg::LDT;
     constexpr int kVecPerRow = BK / 4;               // float4 per tile row
@@ -242,18 +281,40 @@ __global__ __launch_bounds__(256, (min_waves_per_simd<BM, BN, BK, NC>())) void g
     const int wk = wave / (WM * WN);
     const int wm = (wave / WN) % WM, wn = wave % WN;
 
+    // ---- ONE scalar round trip: the tile map and every argument the first tile's loads (and the epilogue's addresses) depend on.
+    //      The empty asm pins them in SGPRs here, so hipcc issues all the s_loads back to back in front of it instead of
+    //      sinking each next to its first use behind the previous one's wait (five dependent rounds before round 4). ----
+    const TileMap t = tmap;
+    const float* const a1_ptr = p.A1;
+    const float* const w0_ptr = p.seg[0].W;
+    const float* const bias0_ptr = p.seg[0].bias;
+    float* const c0_ptr = p.seg[0].C;
+    const float* const a2_shared = p.A2;
+    uint8_t* const zero_rows_ptr = p.zero_rows_out;
+    const int arg_lda1 = p.lda1, arg_lda2 = p.lda2, arg_K1 = p.K1, arg_K2 = p.K2, arg_M = p.M, arg_seg_n = p.seg_n, arg_nseg = p.nseg;
+    // (one statement: one s_waitcnt; "what the epilogue addresses with" rides along -- otherwise one more round trip behind the K loop)
+    asm volatile("" ::"s"(t.nwg), "s"(t.tiles_m), "s"(t.tiles_n_all), "s"(t.tiles_n_per_seg), "s"(t.xcd_pm), "s"(t.pm_shift), "s"(t.sub_m),
+                 "s"(t.sub_n), "s"(t.sub_m_magic), "s"(t.seg_magic), "s"(t.group_m), "s"(t.group_size), "s"(t.gm_last),
+                 "s"(t.group_size_magic), "s"(t.group_m_magic), "s"(t.gm_last_magic), "s"(t.kslice), "s"(a1_ptr), "s"(w0_ptr),
+                 "s"(bias0_ptr), "s"(c0_ptr), "s"(arg_lda1), "s"(arg_K1), "s"(arg_K2), "s"(arg_M), "s"(arg_seg_n), "s"(arg_nseg),
+                 "s"(a2_shared), "s"(zero_rows_ptr), "s"(arg_lda2), "s"(p.R), "s"(p.ldc), "s"(p.ldr), "s"(p.res_mod), "s"(p.act),
+                 "s"(p.part_stride), "s"(p.stats), "s"(p.stats_t), "s"(p.stats_ld));
+
     int tile_m, tile_n_all;
-    tile_coords(tiles_m, group_m, xcd_pm, tile_m, tile_n_all);
-    const int seg = tile_n_all / tiles_n_per_seg;
-    const int tile_n = tile_n_all - seg * tiles_n_per_seg;
+    tile_coords_fast(t, (int)blockIdx.x, tile_m, tile_n_all);
+    const int seg = arg_nseg == 1 ? 0 : fast_div(tile_n_all, t.seg_magic, t.tiles_n_per_seg);
+    const int tile_n = tile_n_all - seg * t.tiles_n_per_seg;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
-    const float* __restrict__ W = p.seg[seg].W;
-    const int K = p.K1 + p.K2;
+    // single-segment products (every decode-step product but q|k|v): the segment's pointers came with the first round trip
+    const float* __restrict__ W = arg_nseg == 1 ? w0_ptr : p.seg[seg].W;
+    const float* __restrict__ seg_bias = arg_nseg == 1 ? bias0_ptr : p.seg[seg].bias;
+    float* __restrict__ seg_C = arg_nseg == 1 ? c0_ptr : p.seg[seg].C;
+    const int K = arg_K1 + arg_K2;
     // Cross-workgroup K split (gridDim.y slices): this workgroup covers [kbase, kbase + K / gridDim.y) and writes a
     // raw partial tile.  It halves / quarters the operand bytes a CU pulls through its L2 port for the M = 1280
     // decode shapes, whose 32x32 tiles are bound by that port rather than by the matrix cores.
-    const int kslice = gridDim.y > 1 ? K / (int)gridDim.y : K;
+    const int kslice = t.kslice;
     const int kbase = (int)blockIdx.y * kslice;
     const int nkt = (kslice + BK - 1) / BK;
 
@@ -273,19 +334,20 @@ __global__ __launch_bounds__(256, (min_waves_per_simd<BM, BN, BK, NC>())) void g
     // the whole K loop and the K position travels in the instruction's scalar offset, so the loop spends no
     // vector instructions on addresses (+4..5 % on the 128x128 loop, tools/gemm_ablation.hip).  Rows past M / N
     // fall outside the descriptor's range and read as zero; a K tail is zeroed when the registers go to LDS.
-    const __amdgpu_buffer_rsrc_t rsrc_a1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.A1), 0, p.M * p.lda1 * 4, 0x00020000);
-    const float* a2 = p.seg[seg].A2 ? p.seg[seg].A2 : p.A2;       // per-segment second block (meshed level gates)
-    const __amdgpu_buffer_rsrc_t rsrc_a2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.K2 ? a2 : p.A1), 0,
-                                                                              p.K2 ? p.M * p.lda2 * 4 : 0, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(W), 0, p.seg_n * K * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_a1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a1_ptr), 0, arg_M * arg_lda1 * 4, 0x00020000);
+    // per-segment second block (meshed level gates); the segment table is only consulted when there IS a second block
+    const float* a2 = arg_K2 ? (p.seg[seg].A2 ? p.seg[seg].A2 : a2_shared) : a1_ptr;
+    const __amdgpu_buffer_rsrc_t rsrc_a2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a2), 0,
+                                                                              arg_K2 ? arg_M * arg_lda2 * 4 : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(W), 0, arg_seg_n * K * 4, 0x00020000);
     int off_a1[Cfg::kLoadA], off_a2[Cfg::kLoadA], off_w[Cfg::kLoadB];
     {
         const int kq = tid % kVecPerRow;
 #pragma unroll
         for (int i = 0; i < Cfg::kLoadA; ++i) {
             const int row = m0 + tid / kVecPerRow + i * kRowsPerPass;
-            off_a1[i] = (row * p.lda1 + kq * 4) * 4;
-            off_a2[i] = (row * p.lda2 + kq * 4) * 4;
+            off_a1[i] = (row * arg_lda1 + kq * 4) * 4;
+            off_a2[i] = (row * arg_lda2 + kq * 4) * 4;
         }
 #pragma unroll
         for (int i = 0; i < Cfg::kLoadB; ++i) off_w[i] = ((n0 + tid / kVecPerRow + i * kRowsPerPass) * K + kq * 4) * 4;
@@ -314,7 +376,7 @@ __global__ __launch_bounds__(256, (min_waves_per_simd<BM, BN, BK, NC>())) void g
     // The loaded registers are first touched here, after the MFMA block of the previous tile, so the
     // global-load latency hides under the matrix work (issue early / write late).
     // K1 fold (GemmArgs::zero_rows_out): the workgroups of the first column tile add up the A rows they stage anyway
-    const bool row_sums = p.zero_rows_out != nullptr && tile_n_all == 0;      // uniform
+    const bool row_sums = zero_rows_ptr != nullptr && tile_n_all == 0;        // uniform
     float rs[Cfg::kLoadA];
 #pragma unroll
     for (int i = 0; i < Cfg::kLoadA; ++i) rs[i] = 0.f;
@@ -483,7 +545,7 @@ __global__ __launch_bounds__(256, (min_waves_per_simd<BM, BN, BK, NC>())) void g
 #pragma unroll
             for (int off = 1; off < kVecPerRow; off <<= 1) v += __shfl_xor(v, off, 64);
             const int row = m0 + tid / kVecPerRow + i * kRowsPerPass;
-            if (tid % kVecPerRow == 0 && row < p.M) p.zero_rows_out[row] = (v == 0.f) ? 1 : 0;
+            if (tid % kVecPerRow == 0 && row < arg_M) zero_rows_ptr[row] = (v == 0.f) ? 1 : 0;
         }
     }
 
@@ -524,7 +586,7 @@ __global__ __launch_bounds__(256, (min_waves_per_simd<BM, BN, BK, NC>())) void g
         }
     }
 
-    store_wave_tiles<Cfg::TM, Cfg::TN>(p, seg, acc[0], m0 + wm * Cfg::kWaveM, n0 + wn * Cfg::kWaveN, lane);
+    store_wave_tiles<Cfg::TM, Cfg::TN>(p, seg_bias, seg_C, acc[0], m0 + wm * Cfg::kWaveM, n0 + wn * Cfg::kWaveN, lane);
 }
 
 // tile order shared by both kernels: super-rows of M tiles when the A panel exceeds an L2, else the 2-D XCD split with
@@ -556,6 +618,28 @@ void tile_order(const GemmArgs& a, int tiles_m, int tiles_n, int* group_m, int* 
     }
 }
 
+// Host side of tile_coords_fast: the divisors of the tile map with their multiply-high magics.
+TileMap make_tile_map(int nwg, int tiles_m, int tiles_n_per_seg, int group_m, int xcd_pm, int kslice) {
+    auto magic = [](int d) { return d > 1 ? (unsigned)(((uint64_t)1 << 32) / (uint64_t)d + 1) : 0u; };
+    TileMap t{};
+    t.nwg = nwg; t.tiles_m = tiles_m; t.tiles_n_all = nwg / tiles_m; t.tiles_n_per_seg = tiles_n_per_seg;
+    t.xcd_pm = xcd_pm; t.kslice = kslice;
+    t.seg_magic = magic(tiles_n_per_seg);
+    if (xcd_pm > 0) {
+        t.pm_shift = xcd_pm == 8 ? 3 : (xcd_pm == 4 ? 2 : (xcd_pm == 2 ? 1 : 0));
+        t.sub_m = tiles_m / xcd_pm; t.sub_n = t.tiles_n_all / (8 / xcd_pm);
+        t.sub_m_magic = magic(t.sub_m);
+        t.group_m = tiles_m; t.group_size = nwg; t.gm_last = tiles_m;       // unused on this path; kept valid
+    } else {
+        t.group_m = group_m; t.group_size = group_m * t.tiles_n_all;
+        const int rest = tiles_m % group_m;
+        t.gm_last = rest ? rest : group_m;
+        t.sub_m = 1; t.sub_n = 1;
+    }
+    t.group_size_magic = magic(t.group_size); t.group_m_magic = magic(t.group_m); t.gm_last_magic = magic(t.gm_last);
+    return t;
+}
+
 template <int BM, int BN, int WM, int WN, int WK, int BK, int NC>
 int launch_config(const GemmArgs& a, hipStream_t stream, const GemmLaunchOpts& opts) {
     using Cfg = TileConfig<BM, BN, WM, WN, WK, BK, NC>;
@@ -571,14 +655,15 @@ int launch_config(const GemmArgs& a, hipStream_t stream, const GemmLaunchOpts& o
     int group_m, xcd_pm;
     tile_order(a, tiles_m, tiles_n, &group_m, &xcd_pm);
     const int slices = a.ksplit > 1 ? a.ksplit : 1;         // K slices run one after the other (gridDim.y is the slow index)
+    const TileMap map = make_tile_map(grid, tiles_m, tiles_n, group_m, xcd_pm, (a.K1 + a.K2) / slices);
     // opts.copies (tuner only): gridDim.z identical copies of the product in one launch (the kernel ignores
     // blockIdx.z), a proxy for "this many batches in flight" that needs no extra streams.
     const dim3 grid3(grid, slices, opts.copies > 1 ? opts.copies : 1);
     if (opts.start && opts.stop)     // kernel-scoped events: the dispatch packet's own begin / end timestamps
         hipExtLaunchKernelGGL((gemm_f32_mfma<BM, BN, WM, WN, WK, BK, NC>), grid3, dim3(256), (uint32_t)lds_bytes, stream,
-                              opts.start, opts.stop, 0, a, tiles_m, tiles_n, group_m, xcd_pm);
+                              opts.start, opts.stop, 0, map, a);
     else
-        hipLaunchKernelGGL((gemm_f32_mfma<BM, BN, WM, WN, WK, BK, NC>), grid3, dim3(256), lds_bytes, stream, a, tiles_m, tiles_n, group_m, xcd_pm);
+        hipLaunchKernelGGL((gemm_f32_mfma<BM, BN, WM, WN, WK, BK, NC>), grid3, dim3(256), lds_bytes, stream, map, a);
     OVC_RETURN_IF_LAUNCH_FAILED();
     return OVC_OK;
 }

@@ -311,5 +311,5 @@ __global__ __launch_bounds__(256) void gemm_split_mfma(GemmArgs p, int tiles_m, 
                         acc[c - 1][i][j][r] = fmaf(acc[c][i][j][r], 1.f / kHalfResidualScale, acc[c - 1][i][j][r]);
     }
 
-    store_wave_tiles<Cfg::TM, Cfg::TN>(p, seg, acc[0], m0 + wm * Cfg::kWaveM, n0 + wn * Cfg::kWaveN, lane);
+    store_wave_tiles<Cfg::TM, Cfg::TN>(p, p.seg[seg].bias, p.seg[seg].C, acc[0], m0 + wm * Cfg::kWaveM, n0 + wn * Cfg::kWaveN, lane);
 }

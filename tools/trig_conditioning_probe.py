@@ -7,7 +7,7 @@ This probe measures it: random object-relation models (the fuzz's draw, trigonom
 by the CPU oracle in fp32 and by the same oracle in fp64; prints the relative L2 errors of the two fp32 results against fp64,
 their ratio, and the same for the box-relation weights alone (``ovc_box_relation_weights`` against ``geometry_weights``).
 
-    python tools/trig_conditioning_probe.py [cases] [seed] [trig: 1 / 0]
+    python tools/trig_conditioning_probe.py [cases] [seed] [trig: 1 / 0] [dlct]
 """
 import os
 import random
@@ -33,7 +33,46 @@ def rel(a, b):
     return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300))
 
 
+def dlct(cases, seed, trig):
+    """The same comparison for the dual-collaborative (DLCT) embedding + encoder (four geometry attentions per layer)."""
+    from helpers import dlct_case
+    from openviic_amd.builders import build_encoder, build_vision_embedding
+    from oracle.dlct import OracleDualEncoder
+    rng = random.Random(seed)
+    rows = []
+    for case in range(cases):
+        heads, d_kv = rng.choice([(2, 32), (4, 16), (4, 32), (8, 8), (8, 16), (2, 64), (1, 64)])
+        d_model = heads * 8 * rng.randint(1, 4) if trig else 32 * rng.randint(1, 6)
+        grid = rng.randint(1, 12)
+        shape = dict(B=rng.randint(1, 4), n_regions=rng.randint(2, 100 if grid > 7 else min(60, 128 - grid * grid)), grid=grid,
+                     d_region=4 * rng.randint(2, 30), d_grid=4 * rng.randint(2, 30), d_model=d_model, heads=heads, d_kv=d_kv,
+                     d_ff=4 * rng.randint(4, 64), layers=rng.randint(1, 3))
+        emb_cfg, enc_cfg, emb_sd, enc_sd, inputs = dlct_case(trig, shape, input_seed=500 + case)
+        region, region_boxes, grid_f, grid_boxes = inputs
+        outs = []
+        for dtype in (torch.float32, torch.float64):
+            orc = OracleDualEncoder(enc_cfg, emb_sd, enc_sd, dtype=dtype)
+            (orf, orm), (ogf, ogm), (or2a, og2a) = orc.embed(region, region_boxes, grid_f, grid_boxes)
+            outs.append(orc.encode(orf, region_boxes, orm, or2a, ogf, grid_boxes, ogm, og2a)[0].double().numpy())
+        cpu, ref = outs
+        emb, enc = build_vision_embedding(emb_cfg).eval(), build_encoder(enc_cfg).eval()
+        emb.load_state_dict(emb_sd)
+        enc.load_state_dict(enc_sd)
+        emb, enc = emb.to("cuda"), enc.to("cuda")
+        with torch.no_grad():
+            (rf, rm), (gf, gm), (r2a, g2a) = emb(*(t.to("cuda") for t in inputs))
+            hip = enc(rf, region_boxes.to("cuda"), rm, r2a, gf, grid_boxes.to("cuda"), gm, g2a)[0].cpu().double().numpy()
+        keep = np.isfinite(ref).all(axis=-1)
+        rows.append((rel(hip[keep], ref[keep]), rel(cpu[keep], ref[keep]), None, 0.0, case, heads, d_kv, d_model, shape["layers"], shape["B"],
+                     shape["n_regions"] + grid * grid))
+    return rows
+
+
 def main():
+    if len(sys.argv) > 4 and sys.argv[4] == "dlct":
+        rows = dlct(int(sys.argv[1]), int(sys.argv[2]), sys.argv[3] != "0")
+        report(rows, "dual-collaborative encoder, trig=%s" % sys.argv[3], len(rows))
+        return
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
     rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
     trig = (sys.argv[3] != "0") if len(sys.argv) > 3 else True
@@ -64,8 +103,12 @@ def main():
         wc = float((w32.double() - w64).abs().max())
         rows.append((e_hip, e_cpu, wh, wc, case, heads, d_kv, d_model, dims["layers"], B, N))
         model._engine = None
+    report(rows, "trig=%d" % trig, cases)
+
+
+def report(rows, title, cases):
     rows.sort(reverse=True)
-    print("trig=%d  %d cases: relative L2 error of the encoder output against fp64 (same weights, same inputs)" % (trig, cases))
+    print("%s  %d cases: relative L2 error of the encoder output against fp64 (same weights, same inputs)" % (title, cases))
     print("   e_hip     e_cpu   ratio | max |dw| hip   cpu  | case heads d_k d_model layers B N")
     for r in rows[:25]:
         print("%.2e  %.2e  %5.2f | %s  %.1e | %s" % (r[0], r[1], r[0] / max(r[1], 1e-300),
