@@ -306,7 +306,9 @@ __global__ __launch_bounds__(256, (min_waves_per_simd<BM, BN, BK, NC>())) void g
     const int tile_n = tile_n_all - seg * t.tiles_n_per_seg;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
-    // single-segment products (every decode-step product but q|k|v): the segment's pointers came with the first round trip
+    // single-segment products (every decode-step product but q|k|v): the segment's pointers came with the first round trip.
+    // (Fetching the first THREE segments' pointers that way as well -- q|k|v -- measured slower: 18.4k against 18.6k captions/s
+    // on one stream, 24.52k against 24.63k on four; the longer first batch delays everything else.)
     const float* __restrict__ W = arg_nseg == 1 ? w0_ptr : p.seg[seg].W;
     const float* __restrict__ seg_bias = arg_nseg == 1 ? bias0_ptr : p.seg[seg].bias;
     float* __restrict__ seg_C = arg_nseg == 1 ? c0_ptr : p.seg[seg].C;

@@ -25,12 +25,21 @@ __global__ __launch_bounds__(256) void layer_norm_rows(const float* __restrict__
                                                        const float* __restrict__ add, int add_rows,
                                                        const uint8_t* __restrict__ zero_rows, float eps,
                                                        float* __restrict__ y, int rows, int d) {
+    // every argument in ONE scalar round trip (hipcc otherwise fetches `rows` for the guard below first and the pointers in a
+    // second, dependent round: the kernel is nothing but a chain of round trips -- gemm.hip, round 4)
+    asm volatile("" ::"s"(x), "s"(part_stride), "s"(bias), "s"(residual), "s"(gamma), "s"(beta), "s"(add), "s"(add_rows), "s"(zero_rows),
+                 "s"(eps), "s"(y), "s"(rows), "s"(d));
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const int nvec = d >> 2;
     float* yrow = y + (size_t)row * d;
-    const bool cleared = zero_rows && zero_rows[row];      // consumed after the row's loads are in flight
+    // The row's "write zeros instead" flag travels WITH the row's loads and is applied as a select on the way out.  (Until round 4
+    // this was an early `if (cleared) { store zeros; return; }` behind the loads in the source -- hipcc moved the test in front of
+    // them and waited for the byte: one whole extra round trip in every launch that takes the flags.)
+    // (an unconditional load from an always-valid address: a load inside `if (zero_rows)` gets a full s_waitcnt at the join)
+    const uint8_t cleared_byte = *(zero_rows ? zero_rows + row : reinterpret_cast<const uint8_t*>(gamma));
+    const bool cleared = zero_rows != nullptr && cleared_byte != 0;
     // column group of (lane, i), clamped in-range: out-of-range lanes load a valid address and are masked later
     int col[kVecs];
 #pragma unroll
@@ -56,10 +65,6 @@ __global__ __launch_bounds__(256) void layer_norm_rows(const float* __restrict__
     for (int i = 0; i < kVecs; ++i) {
         gv[i] = reinterpret_cast<const f32x4*>(gamma)[col[i]];
         bev[i] = reinterpret_cast<const f32x4*>(beta)[col[i]];
-    }
-    if (cleared) {
-        for (int c = lane; c < nvec; c += 64) reinterpret_cast<f32x4*>(yrow)[c] = f32x4{0.f, 0.f, 0.f, 0.f};
-        return;
     }
     f32x4 v[kVecs];
     float sum = 0.f;
@@ -89,6 +94,7 @@ __global__ __launch_bounds__(256) void layer_norm_rows(const float* __restrict__
         if (c < nvec) {
             f32x4 o = (v[i] - mean) * rstd * gv[i] + bev[i];
             if (ar) o += ar[c];
+            if (cleared) o = f32x4{0.f, 0.f, 0.f, 0.f};
             reinterpret_cast<f32x4*>(yrow)[c] = o;
         }
     }
