@@ -128,7 +128,8 @@ __device__ __forceinline__ void tile_coords(int tiles_m, int group_m, int xcd_pm
 // for gridDim, the dynamically indexed segment table -- before its first operand load is issued: 415 instructions and ~2 us of
 // an M = 1280 product's ~11.  Here the launch hands over a TileMap (divisors with their multiply-high magics, gridDim, the K
 // slice length) as the FIRST kernel argument, and the kernel fetches it together with every GemmArgs field the first tile's loads
-// need in ONE scalar round trip.  magic = floor(2^32 / d) + 1: mulhi(x, magic) == x / d for x * d < 2^32 (tile counts: always).
+// need in ONE scalar round trip.  magic = floor(2^32 / d) + 1: mulhi(x, magic) is x / d or x / d + 1 for every x < 2^32 (exact
+// while x * d < 2^32, which a grid of 65 537 tiles in one group already violates), so fast_div corrects it once: exact for any grid.
 struct TileMap {
     int nwg, tiles_m, tiles_n_all, tiles_n_per_seg;
     int xcd_pm, pm_shift, sub_m, sub_n;
@@ -138,7 +139,11 @@ struct TileMap {
     int kslice;
 };
 
-__device__ __forceinline__ int fast_div(int x, unsigned magic, int d) { return d == 1 ? x : (int)__umulhi((unsigned)x, magic); }
+__device__ __forceinline__ int fast_div(int x, unsigned magic, int d) {
+    if (d == 1) return x;
+    const unsigned q = __umulhi((unsigned)x, magic);             // never low, at most one high
+    return (int)(q * (unsigned)d > (unsigned)x ? q - 1 : q);
+}
 
 __device__ __forceinline__ void tile_coords_fast(const TileMap& t, int bid, int& tile_m, int& tile_n_all) {
     const int xcd = bid & 7, q = t.nwg >> 3, r = t.nwg & 7;

@@ -487,6 +487,39 @@ def test_every_tiling_of_a_k_order_class_gives_the_same_bits(M, N, K):
         assert err[104] < 4 * err[1] and err[103] < 8 * err[1], err     # 22 / 24 operand bits: the fp32 path's own error level
 
 
+def test_the_tile_map_is_exact_on_a_grid_of_65793_tiles():
+    """The launcher hands the kernel its divisors as multiply-high magics (gemm.hip: TileMap, fast_div).  floor(2^32 / d) + 1 alone
+    is exact only while tile * d < 2^32: on a grid of 3 x 21 931 = 65 793 tiles in one super-row group the LAST tile (65 792)
+    would come out in group 1 -- outside the product, its corner of the output never written.  fast_div corrects the estimate
+    once (it is never low and at most one high), so every element must be there.  (The smallest such grid the entry points'
+    2 GB buffer limits admit; the model's own products have at most 12 800 tiles.)"""
+    from openviic_amd import native
+    lib = native.load()
+    lib.ovc_profile_kernel_name.restype = __import__("ctypes").c_char_p
+    K, N = 32, 32 * 21931 - 5
+    d = 3 * 21931
+    assert ((d - 1) * ((1 << 32) // d + 1)) >> 32 == 1           # the uncorrected estimate of (d - 1) / d
+    wd = torch.randn(N, K, device=DEV) / math.sqrt(K)
+    bd = torch.randn(N, device=DEV)
+    ran = 0
+    for t, name, chains in _tilings(lib):
+        rows = {"gemm_f32_mfma<32, 32, 1, 1, 4, 32, 1>": 70, "gemm_f32_mfma<64, 32, 2, 1, 2, 32, 2>": 182}.get(name)
+        if rows is None:
+            continue                                  # the instances with 32-column tiles and a K tile of 32; three row tiles each
+        xd = torch.randn(rows, K, device=DEV)
+        y = torch.full((rows, N), float("nan"), device=DEV)
+        rc = lib.ovc_debug_linear_tiling(xd.data_ptr(), K, wd.data_ptr(), bd.data_ptr(), y.data_ptr(), rows, N, t, 1, 1, native.stream_handle())
+        assert rc == 0, name
+        assert bool(torch.isfinite(y[-8:, -27:]).all()), "{}: the last tile was not written".format(name)
+        worst = 0.0
+        for c0 in range(0, N, 1 << 17):               # fp64 reference in column blocks (the whole product would be 1 GB)
+            want = xd.double() @ wd[c0:c0 + (1 << 17)].double().T + bd[c0:c0 + (1 << 17)].double()
+            worst = max(worst, float((y[:, c0:c0 + (1 << 17)].double() - want).abs().max()))
+        assert worst < 1e-5, (name, worst)
+        ran += 1
+    assert ran == 2
+
+
 @pytest.mark.parametrize("M,N,K,ksplit", [(130, 200, 96, 1), (65, 33, 48, 1), (1280, 512, 512, 2), (31, 10201, 64, 1), (640, 40, 2048, 4),
                                           (5, 64, 32, 1), (257, 1536, 128, 1)])
 def test_pre_cut_weight_planes_give_the_bits_of_cutting_in_the_kernel(M, N, K, ksplit):
