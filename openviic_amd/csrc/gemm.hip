@@ -266,6 +266,7 @@ __device__ __forceinline__ void store_wave_tiles(const GemmArgs& p, const float*
 }
 
 #include "gemm_split.h"   // gemm_split_mfma: the opt-in split-precision classes (bf16 planes on the 16-bit matrix path)
+#include "gemm_rows16.h"  // gemm_rows16_f32: the four-chain class for products of up to 64 rows (16-row tiles, v_mfma_f32_16x16x4_f32)
 
 // Registers are capped where residency matters: the M = 1280 decode products come as 1280 workgroups of 32x64 tiles,
 // five per CU -- with more than 96 registers only four are resident and the fifth runs as a second round (35 vs 28 us).
@@ -704,6 +705,25 @@ int launch_split_config(const GemmArgs& a, hipStream_t stream, const GemmLaunchO
     return OVC_OK;
 }
 
+template <int NB>
+int launch_rows16_config(const GemmArgs& a, hipStream_t stream, const GemmLaunchOpts& opts) {
+    const int tiles_m = (a.M + 15) / 16;
+    const int tiles_n = (a.seg_n + 16 * NB - 1) / (16 * NB);
+    const size_t lds_bytes = sizeof(float) * 4 * (16 + 16 * NB) * kRows16Ldt;
+    static std::once_flag attr_once;
+    std::call_once(attr_once, [&] {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_rows16_f32<NB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    });
+    const int kslice = a.K1 / (a.ksplit > 1 ? a.ksplit : 1);
+    const dim3 grid3(tiles_n * a.nseg, tiles_m * (opts.copies > 1 ? opts.copies : 1), a.ksplit > 1 ? a.ksplit : 1);
+    if (opts.start && opts.stop)
+        hipExtLaunchKernelGGL((gemm_rows16_f32<NB>), grid3, dim3(256), (uint32_t)lds_bytes, stream, opts.start, opts.stop, 0, a, tiles_m, tiles_n, kslice);
+    else
+        hipLaunchKernelGGL((gemm_rows16_f32<NB>), grid3, dim3(256), lds_bytes, stream, a, tiles_m, tiles_n, kslice);
+    OVC_RETURN_IF_LAUNCH_FAILED();
+    return OVC_OK;
+}
+
 // bm, bn, wm, wn, wk, bk, nc, planes.  fp32 tilings (planes = 0): chains = wk * nc is the K-order class the instance
 // belongs to; split-precision tilings (planes = the kernel's MODE: 3 = three bf16 planes, 4 = two fp16 planes): class
 // 100 + MODE (kSplitClass).
@@ -729,13 +749,19 @@ constexpr int kSplitClass = 100;
 // a chain of load latencies and fewer, larger tiles halve it
 #define OVC_SPLIT_DEEP(X, first, planes) X(first + 0, 64, 64, 2, 2, 64, planes) X(first + 1, 64, 128, 2, 2, 64, planes)
 #define OVC_SPLIT_TILINGS(X) OVC_SPLIT_SHAPES(X, 17, 3) OVC_SPLIT_SHAPES(X, 22, 4) OVC_SPLIT_DEEP(X, 27, 3) OVC_SPLIT_DEEP(X, 29, 4)
+// small-rows instances of the four-chain class (gemm_rows16.h): id, 16-column blocks per workgroup.  Ids follow the others so that
+// a tuning cache written by an earlier build keeps its meaning.
+#define OVC_ROWS16_TILINGS(X) X(31, 1) X(32, 2)
+constexpr int kRows16MaxM = 64;          // beyond that the 32 x 32 instances' cooperative tiles win anyway
 #define OVC_TILING_INFO(id, bm, bn, wm, wn, wk, bk, nc) {bm, bn, wm, wn, wk, bk, nc, 0},
 #define OVC_SPLIT_INFO(id, bm, bn, wm, wn, bk, planes) {bm, bn, wm, wn, 1, bk, 1, planes},
-constexpr TilingInfo kTilings[] = {OVC_TILINGS(OVC_TILING_INFO) OVC_SPLIT_TILINGS(OVC_SPLIT_INFO)};
+#define OVC_ROWS16_INFO(id, nb) {16, 16 * nb, 1, 1, 4, 32, 1, 0},
+constexpr TilingInfo kTilings[] = {OVC_TILINGS(OVC_TILING_INFO) OVC_SPLIT_TILINGS(OVC_SPLIT_INFO) OVC_ROWS16_TILINGS(OVC_ROWS16_INFO)};
 #undef OVC_TILING_INFO
 #undef OVC_SPLIT_INFO
+#undef OVC_ROWS16_INFO
 constexpr int kNumTilings = sizeof(kTilings) / sizeof(kTilings[0]);
-static_assert(kNumTilings == 31, "tiling ids: 17 fp32 + 14 split-precision (modes 3 and 4)");
+static_assert(kNumTilings == 33, "tiling ids: 17 fp32 + 14 split-precision (modes 3 and 4) + 2 small-rows fp32");
 inline int tiling_chains(int t) { return kTilings[t].planes ? kSplitClass + kTilings[t].planes : kTilings[t].wk * kTilings[t].nc; }
 inline bool class_ok(int c) { return c == 1 || c == 4 || c == kSplitClass + 3 || c == kSplitClass + 4; }
 
@@ -793,8 +819,9 @@ double tiling_cost(const GemmArgs& a, const TilingInfo& t) {
     // split precision: planes (planes + 1) / 2 bf16 MFMAs of 32 cycles per 16-deep step against one fp32 MFMA of 64 per 2
     const int products = t.planes == 4 ? 3 : t.planes * (t.planes + 1) / 2;      // mode 4: two fp16 planes
     const double k_units = t.planes ? K / 16.0 * products * 0.5 : K / 2.0;
-    const double mfma_per_wave = (double)(t.bm / 32) * (t.bn / 32) * k_units / 4.0;
-    const double overhead = 48.0 + (t.bk >= 64 && !t.planes ? 1e9 : 0.0);    // fp32 BK=64 tilings: only when measured or forced
+    // 16-row instances: a wave runs its chain's K / 4 on 16x16x4 instructions of half a slot each, per 16-column block
+    const double mfma_per_wave = t.bm == 16 ? (t.bn / 16) * (K / 16.0) * 0.5 : (double)(t.bm / 32) * (t.bn / 32) * k_units / 4.0;
+    const double overhead = (t.bm == 16 ? 16.0 : 48.0) + (t.bk >= 64 && !t.planes ? 1e9 : 0.0);    // fp32 BK=64 tilings: only when measured or forced
     const double bytes_per_flop = 2.0 * (t.bm + t.bn) / (double)(t.bm * t.bn);   // operand floats per MAC
     const double bw_penalty = 1.0 + 4.0 * bytes_per_flop;                    // 128x128: 1.06, 32x32: 1.5
     return per_cu * (mfma_per_wave * bw_penalty + overhead);
@@ -809,6 +836,7 @@ bool tiling_fits(const GemmArgs& a, int t) {
     if (a.nseg > 1 && a.seg_n % kTilings[t].bn) return false;
     if (a.K2 > 0 && a.K1 % kTilings[t].bk) return false;
     if (a.ksplit > 1 && (a.K1 / a.ksplit) % kTilings[t].bk) return false;     // a slice is a whole number of K tiles
+    if (kTilings[t].bm == 16 && (a.M > kRows16MaxM || a.K2 || a.R || a.stats || a.stats_t || a.zero_rows_out)) return false;   // gemm_rows16.h
     return true;
 }
 
@@ -847,9 +875,11 @@ extern "C" int ovc_debug_force_gemm_tiling(int tiling) {
 const char* ovc_gemm_tiling_name(int tiling) {
 #define OVC_TILING_NAME(id, bm, bn, wm, wn, wk, bk, nc) "gemm_f32_mfma<" #bm ", " #bn ", " #wm ", " #wn ", " #wk ", " #bk ", " #nc ">",
 #define OVC_SPLIT_NAME(id, bm, bn, wm, wn, bk, planes) "gemm_split_mfma<" #bm ", " #bn ", " #wm ", " #wn ", " #bk ", " #planes ">",
-    static const char* names[] = {OVC_TILINGS(OVC_TILING_NAME) OVC_SPLIT_TILINGS(OVC_SPLIT_NAME)};
+#define OVC_ROWS16_NAME(id, nb) "gemm_rows16_f32<" #nb ">",
+    static const char* names[] = {OVC_TILINGS(OVC_TILING_NAME) OVC_SPLIT_TILINGS(OVC_SPLIT_NAME) OVC_ROWS16_TILINGS(OVC_ROWS16_NAME)};
 #undef OVC_TILING_NAME
 #undef OVC_SPLIT_NAME
+#undef OVC_ROWS16_NAME
     return tiling >= 0 && tiling < kNumTilings ? names[tiling] : "";
 }
 
@@ -908,10 +938,13 @@ int ovc_gemm_launch(const GemmArgs& a, hipStream_t stream, const GemmLaunchOpts&
     switch (pick) {
 #define OVC_TILING_CASE(id, bm, bn, wm, wn, wk, bk, nc) case id: return launch_config<bm, bn, wm, wn, wk, bk, nc>(a, stream, opts);
 #define OVC_SPLIT_CASE(id, bm, bn, wm, wn, bk, planes) case id: return launch_split_config<bm, bn, wm, wn, bk, planes>(a, stream, opts);
+#define OVC_ROWS16_CASE(id, nb) case id: return launch_rows16_config<nb>(a, stream, opts);
         OVC_TILINGS(OVC_TILING_CASE)
         OVC_SPLIT_TILINGS(OVC_SPLIT_CASE)
+        OVC_ROWS16_TILINGS(OVC_ROWS16_CASE)
 #undef OVC_TILING_CASE
 #undef OVC_SPLIT_CASE
+#undef OVC_ROWS16_CASE
         default: return OVC_EINVAL;
     }
 }

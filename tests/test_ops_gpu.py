@@ -434,6 +434,8 @@ def _tilings(lib):
         split = re.match(r"gemm_split_mfma<\d+, \d+, \d+, \d+, \d+, (\d+)>", name)
         if split:                                   # opt-in split-precision classes 103 / 104 (16-bit planes)
             out.append((t, name, 100 + int(split.group(1))))
+        elif name.startswith("gemm_rows16_f32<"):   # the four-chain class on 16-row tiles (products of up to 64 rows)
+            out.append((t, name, 4))
         else:
             wk, nc = (int(v) for v in re.match(r"gemm_f32_mfma<\d+, \d+, \d+, \d+, (\d+), \d+, (\d+)>", name).groups())
             out.append((t, name, wk * nc))
@@ -455,8 +457,13 @@ def _linear_by_tiling(lib, native, xd, wd, bd, tiling, ksplit=1):
     return rc, y
 
 
+ROWS16_MAX_M = 64          # gemm.hip: kRows16MaxM
+
+
 @pytest.mark.parametrize("M,N,K", [(130, 200, 96), (65, 33, 36), (1280, 512, 512), (257, 1536, 128), (31, 10201, 64),
-                                   (640, 512, 2048), (5, 64, 32)])
+                                   (640, 512, 2048), (5, 64, 32),
+                                   # the decode products of B = 1 ... 12 at beam 5 (16-row instances, round 4), K tails and N tails
+                                   (5, 512, 512), (40, 2048, 512), (16, 512, 2048), (33, 1536, 512), (7, 100, 36), (64, 48, 1028), (1, 16, 4)])
 def test_every_tiling_of_a_k_order_class_gives_the_same_bits(M, N, K):
     """The order in which a product sums over K is fixed per K-order class (gemm.hip): one chain, or four interleaved
     chains summed ((c0+c1)+c2)+c3 whether the chains live in one wave, two or four.  So every instance of the GEMM
@@ -471,10 +478,13 @@ def test_every_tiling_of_a_k_order_class_gives_the_same_bits(M, N, K):
     want = x.double() @ w.double().T + b.double()
     xd, wd, bd = (t.to(DEV) for t in (x, w, b))
     tilings = _tilings(lib)
-    assert len(tilings) == 31 and {c for _, _, c in tilings} == {1, 4, 103, 104}
+    assert len(tilings) == 33 and {c for _, _, c in tilings} == {1, 4, 103, 104}
     first = {}
     for t, name, chains in tilings:
         rc, got = _linear_by_tiling(lib, native, xd, wd, bd, t)
+        if name.startswith("gemm_rows16") and M > ROWS16_MAX_M:
+            assert rc != 0, name                      # the 16-row instances take products of up to 64 rows
+            continue
         assert rc == 0, name
         _close(got, want, tol=CLASS_TOL[chains], what="%s on %dx%dx%d" % (name, M, N, K))
         if chains in first:
@@ -553,22 +563,25 @@ def test_pre_cut_weight_planes_give_the_bits_of_cutting_in_the_kernel(M, N, K, k
     assert checked >= 6
 
 
+@pytest.mark.parametrize("M", [333, 40, 5])
 @pytest.mark.parametrize("ksplit", [2, 4])
-def test_k_slices_are_bit_identical_across_tilings_and_sum_to_the_product(ksplit):
+def test_k_slices_are_bit_identical_across_tilings_and_sum_to_the_product(ksplit, M):
     """K-split products (engine: the decode-step projections back to d_model): slice s is the product over
     k in [s K/ksplit, (s+1) K/ksplit); every tiling of the class writes the same partial products."""
     from openviic_amd import native
     lib = native.load()
     lib.ovc_profile_kernel_name.restype = __import__("ctypes").c_char_p
-    M, N, K = 333, 512, 1024
+    N, K = 512, 1024
     g = torch.Generator().manual_seed(ksplit)
     x, w = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) / math.sqrt(K)
     xd, wd = x.to(DEV), w.to(DEV)
     first = {}
+    ran = set()
     for t, name, chains in _tilings(lib):
         rc, parts = _linear_by_tiling(lib, native, xd, wd, None, t, ksplit)
-        if rc != 0:           # a slice must be a whole number of this tiling's K tiles
+        if rc != 0:           # a slice must be a whole number of this tiling's K tiles; 16-row instances: up to 64 rows
             continue
+        ran.add(name.split("<")[0])
         ks = K // ksplit
         for s_ in range(ksplit):
             _close(parts[s_], x[:, s_ * ks:(s_ + 1) * ks].double() @ w[:, s_ * ks:(s_ + 1) * ks].double().T, tol=CLASS_TOL[chains],
@@ -578,6 +591,7 @@ def test_k_slices_are_bit_identical_across_tilings_and_sum_to_the_product(ksplit
         else:
             first[chains] = parts
     assert set(first) == {1, 4, 103, 104}
+    assert ("gemm_rows16_f32" in ran) == (M <= ROWS16_MAX_M)
 
 
 def test_tuner_only_ranks_inside_the_class_and_borrows_neighbouring_shapes():

@@ -34,6 +34,8 @@ def tilings(lib):
         v = [int(x) for x in name[name.index("<") + 1:-1].split(",")]
         if "split_mfma" in name:
             out.append((t, "%dx%d b%d p%d" % (v[0], v[1], v[4], v[5]), 100 + v[5]))
+        elif "rows16" in name:                      # gemm_rows16.h: 16-row tiles, the four-chain class, up to 64 rows
+            out.append((t, "16x%d rows16" % (16 * v[0]), 4))
         else:
             out.append((t, "%dx%d w%d b%d c%d" % (v[0], v[1], v[4], v[5], v[6]), v[4] * v[6]))
         t += 1
