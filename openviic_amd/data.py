@@ -109,7 +109,7 @@ def feature_file_loader(paths: Sequence[str], batch_size: int, workers: int, key
                       multiprocessing_context=context if workers > 0 else None, persistent_workers=False)
 
 
-def predict_feature_files(model, vocab, paths: Sequence[str], batch_size: int, beam_size: int = 5, slots: int = 2,
+def predict_feature_files(model, vocab, paths: Sequence[str], batch_size: int, beam_size: int = 5, slots: Optional[int] = None,
                           keys: Optional[Iterable[str]] = None, trusted: bool = False, workers: int = 0,
                           loader_context="forkserver", early_exit: bool = False):
     """The reference's prediction loop (``trainers/vi_trainer.py:241-252``: per batch ``items.to(device)`` ->
@@ -144,7 +144,14 @@ def predict_feature_files(model, vocab, paths: Sequence[str], batch_size: int, b
 
     ``early_exit=True``: decode with ``ovc_beam_search_early`` -- no step is issued once every beam of the batch has ended (real
     captions end well before ``max_len``); same strings.  That call blocks the launching thread until its batch is one step
-    from done, so batches overlap less; with the host side in worker processes that costs little.
+    from done, so batches overlap less; with the host side in worker processes that costs little at large batches -- at the
+    reference's test batch size of 1 it costs more than the steps it saves (4.0 ms per caption against 1.4: the overlap of
+    four searches is worth more than half a search; tools/b1_loop_probe.py).
+
+    ``slots``: batches in flight, each on its own decode stream.  Default: 4 for batches of up to 32 images, 2 above.  A small
+    batch is a chain of ~730 dependent launches of a few workgroups each -- four of them overlap almost freely (B = 1, files ->
+    strings, 8 workers: 430 captions/s with two streams, 725 with four, fewer again with six or eight: the hardware queues),
+    a batch of 256 fills the chip with two.
     """
     import sys
     import time
@@ -158,7 +165,7 @@ def predict_feature_files(model, vocab, paths: Sequence[str], batch_size: int, b
     if device.type != "cuda":
         raise RuntimeError("predict_feature_files needs the model on a HIP device; there is no CPU path")
     keys = tuple(keys) if keys is not None else None
-    slots = max(1, int(slots))
+    slots = (4 if batch_size <= 32 else 2) if slots is None else max(1, int(slots))
     state = getattr(model, "_predict_pipeline", None)           # streams and pinned buffers live as long as the model:
     if state is None or len(state["decode"]) < slots:           # a fresh stream would mean a fresh workspace and graph
         state = model._predict_pipeline = {"copy": torch.cuda.Stream(device=device),
