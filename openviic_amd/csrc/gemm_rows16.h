@@ -3,7 +3,7 @@
 // The reference's own prediction loop decodes ONE image at a time (trainers/base_trainer.py:75-80): M = B * beam = 5 rows per
 // decode-step product, 40 at B = 8.  The 32 x 32 instances of gemm_f32_mfma spend 6.6 us on such a launch whatever the tiling
 //  while a dependent launch that reads its predecessor's output and writes costs 1.75 us
-// (tools/launch_floor_probe.hip): the kernel's own latency -- a cooperative tile load, two barriers per K tile, a 64-MFMA chain of
+// (tools/phase_floor_probe.hip): the kernel's own latency -- a cooperative tile load, two barriers per K tile, a 64-MFMA chain of
 // v_mfma_f32_32x32x2_f32 per wave of which 27 rows in 32 are padding -- is what a 5-row product pays for.  This instance:
 //
 //   * 16-row tiles on v_mfma_f32_16x16x4_f32: the SAME dependent fma chain per output element (k ascending, four k per

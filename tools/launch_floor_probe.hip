@@ -1,70 +1,50 @@
-// What does ONE dependent launch cost in a replayed hipGraph, whatever the kernel does?  (B = 1 in <= 2.0 ms.)
-// Chains of 1000 dependent kernel nodes, replayed; ns per node:
-//   empty        one workgroup, no memory access
-//   touch W      W workgroups of 256 threads; each thread reads one float4 the PREVIOUS node wrote (another workgroup's, so the
-//                line comes from another CU / XCD) and writes one: the least a phase of a decode step does
-//   gemv W       the same plus a 512-deep dot product per thread against a weight row that stays in L2 (2 KB per thread):
-//                a stand-in for a 5-row product's own work
-// A decode step at B = 1 is a sequence of phases in which every output needs ALL outputs of the phase before (projection ->
-// attention over all heads -> projection -> LayerNorm over the whole row -> ...): one launch (or one grid barrier) per phase.
-//   hipcc -O3 --offload-arch=gfx950 tools/launch_floor_probe.hip -o tools/launch_floor_probe.bin
+// Where does the ~5 us floor of a small kernel come from?  Dependent chains of (a) empty kernels, (b) kernels whose
+// workgroups do one cold 16-byte load per thread and a store, (c) the same from an L2-hot buffer; 640 and 320
+// workgroups of 256 threads, plain stream order and hipGraph replay.  Prints ns per launch.
 #include <hip/hip_runtime.h>
 #include <cstdio>
-
-__global__ void empty_kernel() {}
-
-__global__ __launch_bounds__(256) void touch_kernel(const float4* __restrict__ in, float4* __restrict__ out, int n) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    const int j = (i + 4096 + 17) % n;                       // another workgroup's element
-    float4 v = in[j];
-    v.x += 1.f;
-    out[i] = v;
+#include <vector>
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__global__ void empty_kernel(float*) {}
+__global__ void touch_kernel(const f32x4* __restrict__ in, f32x4* __restrict__ out, size_t stride4) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    out[i] = in[i + stride4];
 }
-
-__global__ __launch_bounds__(256) void gemv_kernel(const float4* __restrict__ in, const float4* __restrict__ w, float4* __restrict__ out, int n) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    const int j = (i + 4096 + 17) % n;
-    float4 v = in[j];
-    const float4* row = w + (size_t)(i % 2048) * 128;        // 2 KB per thread, 4 MB in all: L2-resident after the first node
-    float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
-#pragma unroll 8
-    for (int k = 0; k < 128; ++k) {
-        const float4 a = row[k];
-        acc0 = fmaf(a.x, v.x, acc0); acc1 = fmaf(a.y, v.y, acc1); acc2 = fmaf(a.z, v.z, acc2); acc3 = fmaf(a.w, v.w, acc3);
-    }
-    out[i] = float4{acc0, acc1, acc2, acc3};
-}
-
-int main() {
-    const int n_nodes = 1000, max_wg = 256, n = max_wg * 256;
-    hipStream_t s; (void)hipStreamCreate(&s);
-    float4 *a, *b, *w;
-    (void)hipMalloc(&a, n * sizeof(float4)); (void)hipMalloc(&b, n * sizeof(float4)); (void)hipMalloc(&w, 2048 * 128 * sizeof(float4));
-    (void)hipMemset(a, 0, n * sizeof(float4)); (void)hipMemset(b, 0, n * sizeof(float4)); (void)hipMemset(w, 0, 2048 * 128 * sizeof(float4));
-    auto chain = [&](int kind, int wgs) {
+template <typename F> static float time_chain(F launch, int n, hipStream_t s, bool graph) {
+    hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    float ms = 0;
+    if (!graph) {
+        for (int i = 0; i < 20; ++i) launch(i);
+        (void)hipEventRecord(e0, s);
+        for (int i = 0; i < n; ++i) launch(i);
+        (void)hipEventRecord(e1, s); (void)hipEventSynchronize(e1);
+        (void)hipEventElapsedTime(&ms, e0, e1);
+    } else {
         hipGraph_t g; hipGraphExec_t ge;
         (void)hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal);
-        for (int i = 0; i < n_nodes; ++i) {
-            float4* in = (i & 1) ? b : a; float4* out = (i & 1) ? a : b;
-            if (kind == 0) hipLaunchKernelGGL(empty_kernel, dim3(1), dim3(64), 0, s);
-            else if (kind == 1) hipLaunchKernelGGL(touch_kernel, dim3(wgs), dim3(256), 0, s, in, out, wgs * 256);
-            else hipLaunchKernelGGL(gemv_kernel, dim3(wgs), dim3(256), 0, s, in, w, out, wgs * 256);
-        }
+        for (int i = 0; i < n; ++i) launch(i);
         (void)hipStreamEndCapture(s, &g); (void)hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
-        hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
         (void)hipGraphLaunch(ge, s); (void)hipStreamSynchronize(s);
-        float best = 1e30f;
-        for (int rep = 0; rep < 5; ++rep) {
-            (void)hipEventRecord(e0, s); (void)hipGraphLaunch(ge, s); (void)hipEventRecord(e1, s); (void)hipEventSynchronize(e1);
-            float ms; (void)hipEventElapsedTime(&ms, e0, e1);
-            if (ms < best) best = ms;
-        }
+        (void)hipEventRecord(e0, s); (void)hipGraphLaunch(ge, s); (void)hipEventRecord(e1, s); (void)hipEventSynchronize(e1);
+        (void)hipEventElapsedTime(&ms, e0, e1);
         (void)hipGraphExecDestroy(ge); (void)hipGraphDestroy(g);
-        return best * 1e6f / n_nodes;
-    };
-    printf("dependent kernel nodes in a replayed hipGraph, ns per node (best of 5 replays of 1000 nodes)\n");
-    printf("  empty kernel (1 workgroup)            %6.0f\n", chain(0, 1));
-    for (int wgs : {8, 32, 64, 256}) printf("  touch, %3d workgroups                 %6.0f\n", wgs, chain(1, wgs));
-    for (int wgs : {8, 32, 64, 256}) printf("  touch + 512-deep dot, %3d workgroups  %6.0f\n", wgs, chain(2, wgs));
+    }
+    return ms * 1e6f / n;
+}
+int main() {
+    hipStream_t s; (void)hipStreamCreate(&s);
+    const size_t big = (size_t)1 << 30;                       // 1 GiB: every launch reads a different 2.6 MB window (cold)
+    f32x4 *in, *out; (void)hipMalloc(&in, big); (void)hipMalloc(&out, 640 * 256 * 16);
+    (void)hipMemset(in, 0, big);
+    const int n = 400;
+    for (int wgs : {320, 640}) {
+        for (int graph = 0; graph < 2; ++graph) {
+            const float e = time_chain([&](int) { hipLaunchKernelGGL(empty_kernel, dim3(wgs), dim3(256), 0, s, (float*)out); }, n, s, graph);
+            const float cold = time_chain([&](int i) { hipLaunchKernelGGL(touch_kernel, dim3(wgs), dim3(256), 0, s, in, out, (size_t)(i % 300) * 640 * 256); }, n, s, graph);
+            const float hot = time_chain([&](int) { hipLaunchKernelGGL(touch_kernel, dim3(wgs), dim3(256), 0, s, in, out, (size_t)0); }, n, s, graph);
+            printf("%3d workgroups, %s: empty %.0f ns, one cold load + store %.0f ns, one L2-hot load + store %.0f ns per dependent launch\n",
+                   wgs, graph ? "hipGraph replay" : "stream launches", e, cold, hot);
+        }
+    }
     return 0;
 }
