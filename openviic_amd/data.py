@@ -150,7 +150,7 @@ def predict_feature_files(model, vocab, paths: Sequence[str], batch_size: int, b
 
     ``slots``: batches in flight, each on its own decode stream.  Default: 4 for batches of up to 32 images, 2 above.  A small
     batch is a chain of ~730 dependent launches of a few workgroups each -- four of them overlap almost freely (B = 1, files ->
-    strings, 8 workers: 430 captions/s with two streams, 725 with four, fewer again with six or eight: the hardware queues),
+    strings, 8 workers: 430 captions/s with two streams, 725 with four, 270-390 with five to eight whatever GPU_MAX_HW_QUEUES is),
     a batch of 256 fills the chip with two.
     """
     import sys
