@@ -284,7 +284,7 @@ const char* ovc_profile_kernel_name(int tiling);   /* "" past the last tiling */
  *   kchains = 1   one fmaf chain over k (ovc_linear; the engine's M = B*N encoder-side products, and the fp32 engine's
  *                 vocabulary projection, which runs transposed -- M = V rows);
  *   kchains = 4   four interleaved chains summed in chain order (the engine's M = B*beam decode-step products; products
- *                 of up to 64 rows -- the reference's own loop decodes one image at a time -- have instances on 16-row
+ *                 of up to 112 rows -- the reference's own loop decodes one image at a time -- have instances on 16-row
  *                 tiles, gemm_rows16_f32: v_mfma_f32_16x16x4_f32 carries the same fma chain per element, same bits);
  *   ksplit  = s   K cut into s contiguous slices whose raw partial products the consuming LayerNorm sums in
  *                 slice order (engine only; a fixed function of K).

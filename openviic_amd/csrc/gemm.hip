@@ -266,7 +266,7 @@ __device__ __forceinline__ void store_wave_tiles(const GemmArgs& p, const float*
 }
 
 #include "gemm_split.h"   // gemm_split_mfma: the opt-in split-precision classes (bf16 planes on the 16-bit matrix path)
-#include "gemm_rows16.h"  // gemm_rows16_f32: the four-chain class for products of up to 64 rows (16-row tiles, v_mfma_f32_16x16x4_f32)
+#include "gemm_rows16.h"  // gemm_rows16_f32: the four-chain class for products of up to 112 rows (16-row tiles, v_mfma_f32_16x16x4_f32)
 
 // Registers are capped where residency matters: the M = 1280 decode products come as 1280 workgroups of 32x64 tiles,
 // five per CU -- with more than 96 registers only four are resident and the fifth runs as a second round (35 vs 28 us).
@@ -752,7 +752,8 @@ constexpr int kSplitClass = 100;
 // small-rows instances of the four-chain class (gemm_rows16.h): id, 16-column blocks per workgroup.  Ids follow the others so that
 // a tuning cache written by an earlier build keeps its meaning.
 #define OVC_ROWS16_TILINGS(X) X(31, 1) X(32, 2)
-constexpr int kRows16MaxM = 64;          // beyond that the 32 x 32 instances' cooperative tiles win anyway
+constexpr int kRows16MaxM = 112;         // B <= 22 at beam 5 (a B = 25 search was no faster with them: 5.03 against 4.95 ms; B = 20: 4.78 against 4.97).  From ~80 rows on only the narrow products still win on these instances
+                                         // (tools/gemm_bench.py small, rows 64 / 80 / 128: 1280-column-tile grids lose to the 32 x 32 tiles); the tuner ranks
 #define OVC_TILING_INFO(id, bm, bn, wm, wn, wk, bk, nc) {bm, bn, wm, wn, wk, bk, nc, 0},
 #define OVC_SPLIT_INFO(id, bm, bn, wm, wn, bk, planes) {bm, bn, wm, wn, 1, bk, 1, planes},
 #define OVC_ROWS16_INFO(id, nb) {16, 16 * nb, 1, 1, 4, 32, 1, 0},

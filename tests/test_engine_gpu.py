@@ -358,15 +358,15 @@ def test_results_do_not_depend_on_the_gemm_tiling():
             t += 1
     finally:
         lib.ovc_debug_force_gemm_tiling(-1)
-    assert t == 33          # 17 fp32 instances + 14 of the split-precision classes (no-ops here: another class is never used) + 2 of 16 rows (products of up to 64 rows: none here)
+    assert t == 33          # 17 fp32 instances + 14 of the split-precision classes (no-ops here: another class is never used) + 2 of 16 rows (products of up to 112 rows: none here)
 
 
 @pytest.mark.parametrize("variant", ["standard_transformer", "meshed_memory_transformer"])
 def test_small_batches_on_the_16_row_products_decode_the_bits_of_the_32_row_ones(variant):
     """The reference's own prediction loop decodes one image at a time (trainers/base_trainer.py:75-80): 5 rows per decode-step
-    product.  Products of up to 64 rows have their own instances of the four-chain class (gemm_rows16.h: 16-row tiles on
+    product.  Products of up to 112 rows have their own instances of the four-chain class (gemm_rows16.h: 16-row tiles on
     v_mfma_f32_16x16x4_f32, one global round trip).  Same class, same bits: B = 1, 3, 8, 12 decoded with each 16-row instance
-    forced, with a 32-row instance forced, and as rows of a B = 16 batch (80 rows: never on the 16-row instances) -- ids and
+    forced, with a 32-row instance forced, and as rows of a B = 32 batch (160 rows: never on the 16-row instances) -- ids and
     log-probabilities identical."""
     from openviic_amd import native
     from openviic_amd.engine import CaptionEngine
@@ -377,15 +377,15 @@ def test_small_batches_on_the_16_row_products_decode_the_bits_of_the_32_row_ones
         names[lib.ovc_profile_kernel_name(t).decode()] = t
         t += 1
     forced = [names["gemm_rows16_f32<1>"], names["gemm_rows16_f32<2>"], names["gemm_f32_mfma<32, 32, 1, 1, 4, 32, 1>"]]
-    cfg, vocab, sd, feats, boxes = full_case(variant, 16)
+    cfg, vocab, sd, feats, boxes = full_case(variant, 32)
     model = device_model(cfg, vocab, sd)
     engine = CaptionEngine(model)
     engine.use_graph = False            # a captured graph would keep the kernels it was captured with
     x = feats.cuda()
     with torch.no_grad():
-        whole_ids, whole_lp = engine.beam_search(x, None, 16, 5)
+        whole_ids, whole_lp = engine.beam_search(x, None, 32, 5)
     try:
-        for B in (1, 3, 8, 12):
+        for B in (1, 3, 8, 12, 20, 22):
             for tiling in forced:
                 assert lib.ovc_debug_force_gemm_tiling(tiling) == 0
                 with torch.no_grad():

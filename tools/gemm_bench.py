@@ -17,7 +17,7 @@ DECODE = [  # (M, N, K, kchains, ksplit, note)
     (1280, 10201, 512, 4, 1, "vocab"), (256, 512, 512, 4, 1, "t=0 proj"), (256, 10201, 512, 4, 1, "t=0 vocab"),
 ]
 # the reference's own operating points (B = 1 and B = 8 at beam 5: 5 and 40 decode rows; base_trainer.py:75-80)
-SMALL = [(rows, n, k, 4, ks, "%s rows=%d" % (name, rows)) for rows in (5, 40)
+SMALL = [(rows, n, k, 4, ks, "%s rows=%d" % (name, rows)) for rows in [int(r) for r in os.environ.get("OVC_BENCH_ROWS", "5,40").split(",")]
          for n, k, ks, name in ((512, 512, 1, "cross-q"), (512, 512, 2, "o-proj /2"), (1536, 512, 1, "qkv"), (2048, 512, 1, "ffn1"),
                                 (512, 2048, 4, "ffn2 /4"))]
 ENCODER = [
@@ -34,7 +34,7 @@ def tilings(lib):
         v = [int(x) for x in name[name.index("<") + 1:-1].split(",")]
         if "split_mfma" in name:
             out.append((t, "%dx%d b%d p%d" % (v[0], v[1], v[4], v[5]), 100 + v[5]))
-        elif "rows16" in name:                      # gemm_rows16.h: 16-row tiles, the four-chain class, up to 64 rows
+        elif "rows16" in name:                      # gemm_rows16.h: 16-row tiles, the four-chain class, up to 112 rows
             out.append((t, "16x%d rows16" % (16 * v[0]), 4))
         else:
             out.append((t, "%dx%d w%d b%d c%d" % (v[0], v[1], v[4], v[5], v[6]), v[4] * v[6]))
