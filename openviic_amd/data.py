@@ -86,6 +86,120 @@ def collate_feature_fields(items: Sequence[dict]) -> dict:
     return dict(InstanceList([Instance(**fields) for fields in items]))
 
 
+def _identity(batch):
+    return batch
+
+
+class FeatureBatchDataset:
+    """One item = one whole BATCH (``paths[b * batch_size : (b + 1) * batch_size]``), collated by the worker that read its files
+    STRAIGHT INTO slot ``b % nslots`` of a ring of shared-memory buffers which the parent has page-locked for the GPU
+    (``_SharedPinnedRing``): the worker's collate is the only copy on the host -- the parent receives a slot number and shapes and
+    starts the copy to the device.  A field that does not fit its slot (more regions than the ring was sized for), is not
+    float32, or has no ring, comes back as an ordinary tensor through the loader's own shared-memory hand-off, zero-padded like
+    ``InstanceList`` does it.  Used with ``DataLoader(batch_size=None)``: at most ``prefetch_factor * workers`` batches are being
+    written ahead of the one the parent fetched last, which is what the ring's length is chosen against."""
+
+    def __init__(self, paths: Sequence[str], batch_size: int, keys, trusted: bool, ring: dict, nslots: int):
+        self.paths, self.batch_size = list(paths), int(batch_size)
+        self.keys, self.trusted = (tuple(keys) if keys is not None else None), trusted
+        self.ring, self.nslots = ring, int(nslots)
+
+    def __len__(self) -> int:
+        return (len(self.paths) + self.batch_size - 1) // self.batch_size
+
+    def __getitem__(self, b: int) -> dict:
+        import torch
+        from .instance import _pad_rows
+        items = [_fields_from_file(path, self.keys, self.trusted) for path in self.paths[b * self.batch_size:(b + 1) * self.batch_size]]
+        slot = b % self.nslots
+        out = {"filename": [item["filename"] for item in items]}
+        for name in items[0]:
+            if name == "filename":
+                continue
+            arrays = [item[name] for item in items]
+            first = arrays[0]
+            buffers = self.ring.get(name)
+            regular = first.ndim >= 1 and all(a.dtype == np.float32 and a.shape[1:] == first.shape[1:] for a in arrays)
+            if buffers is not None and regular:
+                longest = max(a.shape[0] for a in arrays)
+                shape = (len(arrays), longest) + tuple(first.shape[1:])
+                numel = int(np.prod(shape))
+                if numel <= buffers[slot].numel():
+                    dst = buffers[slot][:numel].view(shape).numpy()
+                    for i, a in enumerate(arrays):
+                        dst[i, :a.shape[0]] = a
+                        if a.shape[0] < longest:
+                            dst[i, a.shape[0]:] = 0             # the reference's zero rows = padding (utils/instance.py:156-171)
+                    out[name] = ("__ring__", slot, shape)
+                    continue
+            out[name] = _pad_rows([torch.as_tensor(a) for a in arrays])
+        return out
+
+
+class _SharedPinnedRing:
+    """``nslots`` float32 buffers per field in SHARED memory (worker processes map them) that this process has registered with the
+    HIP runtime as page-locked (``hipHostRegister`` through ``torch.cuda.cudart()``): a worker's collate lands where the copy
+    engine reads.  Lives as long as the model's prediction pipeline; registration happens once (it updates the GPU's page
+    tables -- not something to do per batch)."""
+
+    def __init__(self, capacities: dict, nslots: int):
+        import torch
+        self.nslots, self.capacities = int(nslots), dict(capacities)
+        self.buffers, self._registered = {}, []
+        runtime = torch.cuda.cudart()
+        for name, numel in capacities.items():
+            self.buffers[name] = []
+            for _ in range(self.nslots):
+                buf = torch.empty(max(int(numel), 1), dtype=torch.float32).share_memory_()
+                err = runtime.cudaHostRegister(buf.data_ptr(), buf.numel() * 4, 0)
+                if int(err) != 0:
+                    self.release()
+                    raise RuntimeError("hipHostRegister failed with code {}".format(int(err)))
+                self._registered.append(buf)
+                self.buffers[name].append(buf)
+
+    def fits(self, capacities: dict, nslots: int) -> bool:
+        return nslots <= self.nslots and all(self.capacities.get(name, -1) >= numel for name, numel in capacities.items())
+
+    def release(self):
+        import torch
+        runtime = torch.cuda.cudart()
+        for buf in self._registered:
+            runtime.cudaHostUnregister(buf.data_ptr())
+        self._registered, self.buffers = [], {}
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:                                  # interpreter shutdown
+            pass
+
+
+def _ring_capacities(paths: Sequence[str], batch_size: int, keys, trusted: bool, headroom: float = 1.25) -> dict:
+    """Floats per slot and field, from a sample of the files: batch_size x (longest sampled first dimension x headroom) x the rest."""
+    sample = [paths[i] for i in sorted({int(j * (len(paths) - 1) / 15) for j in range(16)})] if len(paths) > 16 else list(paths)
+    longest, rest = {}, {}
+    for path in sample:
+        for name, array in _fields_from_file(path, keys, trusted).items():
+            if name == "filename" or array.ndim < 1 or array.dtype != np.float32:
+                continue
+            longest[name] = max(longest.get(name, 0), array.shape[0])
+            rest[name] = int(np.prod(array.shape[1:])) if array.ndim > 1 else 1
+    return {name: int(batch_size * (int(longest[name] * headroom) + 1) * rest[name]) for name in longest}
+
+
+def _worker_context(context):
+    """``"forkserver"`` -> a forkserver context with torch pre-loaded.  Workers are then forked from a small server process that
+    has torch and this module imported already: they come up in milliseconds (spawned interpreters import torch one after the
+    other -- the parent blocks on each worker's start-up pipe -- 0.9 s per worker), and nothing is ever fork()ed from the caller's
+    own (HIP-initialised) process."""
+    if context == "forkserver":
+        import multiprocessing
+        context = multiprocessing.get_context("forkserver")
+        context.set_forkserver_preload(["torch", "numpy", __name__])
+    return context
+
+
 def feature_file_loader(paths: Sequence[str], batch_size: int, workers: int, keys: Optional[Iterable[str]] = None,
                         trusted: bool = False, pin_memory: bool = False, prefetch_factor: int = 2, context=None):
     """``DataLoader`` over feature files the way the reference feeds its loops (``trainers/base_trainer.py:40-80``: worker
@@ -96,13 +210,7 @@ def feature_file_loader(paths: Sequence[str], batch_size: int, workers: int, key
     pinned memory per batch, and every such allocation updates the GPU's page tables under the running decode (measured: the
     decode of a batch then takes 183 ms instead of 11)."""
     from torch.utils.data import DataLoader
-    if workers > 0 and context == "forkserver":
-        # Workers are forked from a small server process that has torch and this module imported already: they come up in
-        # milliseconds (spawned interpreters import torch one after the other -- the parent blocks on each worker's start-up
-        # pipe -- 0.9 s per worker), and nothing is ever fork()ed from the caller's own (HIP-initialised) process.
-        import multiprocessing
-        context = multiprocessing.get_context("forkserver")
-        context.set_forkserver_preload(["torch", "numpy", __name__])
+    context = _worker_context(context) if workers > 0 else None
     return DataLoader(FeatureFileDataset(paths, keys, trusted), batch_size=batch_size, shuffle=False, num_workers=workers,
                       collate_fn=collate_feature_fields, pin_memory=pin_memory and workers > 0,
                       prefetch_factor=prefetch_factor if workers > 0 else None,
@@ -111,7 +219,7 @@ def feature_file_loader(paths: Sequence[str], batch_size: int, workers: int, key
 
 def predict_feature_files(model, vocab, paths: Sequence[str], batch_size: int, beam_size: int = 5, slots: Optional[int] = None,
                           keys: Optional[Iterable[str]] = None, trusted: bool = False, workers: int = 0,
-                          loader_context="forkserver", early_exit: bool = False):
+                          loader_context="forkserver", early_exit: bool = False, direct: bool = True):
     """The reference's prediction loop (``trainers/vi_trainer.py:241-252``: per batch ``items.to(device)`` ->
     ``model.beam_search(items, batch_size, beam_size, out_size=1)`` -> ``decode_caption`` -> duplicate collapse) as a
     software pipeline on ONE host thread:
@@ -142,16 +250,23 @@ def predict_feature_files(model, vocab, paths: Sequence[str], batch_size: int, b
     (tools/loader_stall_probe.py; a pure-Python thread holding the GIL costs about as much -- the copier thread's Python work
     is a few calls per batch).
 
+    ``direct=True`` (default, with workers): the workers collate each batch STRAIGHT INTO a ring of shared-memory buffers that this
+    process has page-locked for the GPU (``FeatureBatchDataset`` / ``_SharedPinnedRing``) -- no copier thread, no second copy on the
+    host: the launching thread receives a slot number and starts the copy to the device.  The ring has
+    ``2 * workers + slots + 2`` slots of the batch's size (2.3 GB at B = 256 with 8 workers), allocated and registered once per
+    model.  ``direct=False`` keeps the copier thread of the first version (a collated batch comes back through the loader's own
+    shared memory and is copied into pinned buffers: 8 ms of a 22 ms batch period at B = 256).
+
     ``early_exit=True``: decode with ``ovc_beam_search_early`` -- no step is issued once every beam of the batch has ended (real
     captions end well before ``max_len``); same strings.  That call blocks the launching thread until its batch is one step
     from done, so batches overlap less; with the host side in worker processes that costs little at large batches -- at the
     reference's test batch size of 1 it costs more than the steps it saves (4.0 ms per caption against 1.4: the overlap of
     four searches is worth more than half a search; tools/b1_loop_probe.py).
 
-    ``slots``: batches in flight, each on its own decode stream.  Default: 4 for batches of up to 32 images, 2 above.  A small
-    batch is a chain of ~730 dependent launches of a few workgroups each -- four of them overlap almost freely (B = 1, files ->
-    strings, 8 workers: 430 captions/s with two streams, 725 with four, 270-390 with five to eight whatever GPU_MAX_HW_QUEUES is),
-    a batch of 256 fills the chip with two.
+    ``slots``: batches in flight, each on its own decode stream.  Default 4: a small batch is a chain of ~730 dependent launches
+    of a few workgroups each -- four of them overlap almost freely (B = 1, files -> strings, 8 workers: 430 captions/s with two
+    streams, 725 with four) --, a batch of 256 fills the chip better with four than with two (19.0k against 16.8k captions/s
+    with the shared ring), and a fifth search serialises with the others whatever GPU_MAX_HW_QUEUES is (270-390 at B = 1).
     """
     import sys
     import time
@@ -165,7 +280,7 @@ def predict_feature_files(model, vocab, paths: Sequence[str], batch_size: int, b
     if device.type != "cuda":
         raise RuntimeError("predict_feature_files needs the model on a HIP device; there is no CPU path")
     keys = tuple(keys) if keys is not None else None
-    slots = (4 if batch_size <= 32 else 2) if slots is None else max(1, int(slots))
+    slots = 4 if slots is None else max(1, int(slots))
     state = getattr(model, "_predict_pipeline", None)           # streams and pinned buffers live as long as the model:
     if state is None or len(state["decode"]) < slots:           # a fresh stream would mean a fresh workspace and graph
         state = model._predict_pipeline = {"copy": torch.cuda.Stream(device=device),
@@ -195,7 +310,45 @@ def predict_feature_files(model, vocab, paths: Sequence[str], batch_size: int, b
 
     ring_of = {}                                     # decode slot -> staging-ring entry of the batch in flight on it
     free_ring = None
-    if workers > 0:
+    source = None
+    if workers > 0 and direct:
+        # The workers write each collated batch into a slot of a shared, page-locked ring; batch b uses slot b % nslots.  The
+        # loader keeps at most 2 * workers batches in flight ahead of the one fetched last, and a slot's previous batch (nslots
+        # earlier) finished decoding before the batch 2 * workers + 1 after it is fetched (finish() below): nothing is overwritten
+        # while the copy engine may still read it.
+        try:
+            from torch.utils.data import DataLoader
+            prefetch = 2
+            nslots = prefetch * workers + slots + 2
+            capacities = _ring_capacities(paths, batch_size, keys, trusted)
+            shared = state.get("shared_ring")
+            if shared is None or not shared.fits(capacities, nslots):
+                if shared is not None:
+                    torch.cuda.synchronize(device)
+                    shared.release()
+                shared = state["shared_ring"] = _SharedPinnedRing(capacities, nslots)
+            batches = DataLoader(FeatureBatchDataset(paths, batch_size, keys, trusted, shared.buffers, shared.nslots), batch_size=None,
+                                 shuffle=False, num_workers=workers, prefetch_factor=prefetch, collate_fn=_identity,
+                                 multiprocessing_context=_worker_context(loader_context), persistent_workers=False)
+
+            def ring_source():
+                for fields in batches:
+                    host = InstanceList()
+                    for name, value in fields.items():
+                        if isinstance(value, (tuple, list)) and len(value) == 3 and value[0] == "__ring__":
+                            _, ring_slot, shape = value
+                            numel = 1
+                            for extent in shape:
+                                numel *= int(extent)
+                            host[name] = shared.buffers[name][ring_slot][:numel].view(tuple(shape))
+                        else:
+                            host[name] = value
+                    yield None, host
+            source = ring_source()
+        except (RuntimeError, AttributeError) as error:      # no hipHostRegister in this build of torch, or it refused: the copier path
+            print("[predict] shared page-locked ring unavailable ({}); using the copier thread".format(error), file=sys.stderr)
+            source = None
+    if workers > 0 and source is None:
         # The host side in worker processes: a copier thread takes each collated batch out of the loader's shared memory and
         # into a ring of pinned buffers that live as long as the model (one plain memcpy, GIL released), the launching thread
         # only ever sees pinned tensors.  Ring entries return to the copier when their batch's strings have been built.
@@ -258,7 +411,7 @@ def predict_feature_files(model, vocab, paths: Sequence[str], batch_size: int, b
                     return
                 yield item
         source = staged_source()
-    else:
+    elif source is None:
         source = ((None, batch_from_feature_files(paths[first:first + batch_size], keys=keys, trusted=trusted))
                   for first in range(0, len(paths), batch_size))
     index = 0
@@ -275,7 +428,7 @@ def predict_feature_files(model, vocab, paths: Sequence[str], batch_size: int, b
                 with torch.cuda.stream(copy_stream):
                     for name, value in host.items():
                         if isinstance(value, torch.Tensor):
-                            if entry is not None:          # already in the staging ring's pinned memory
+                            if entry is not None or value.is_pinned():     # already in page-locked memory (the staging ring / the shared ring)
                                 stage = value
                             else:
                                 stage = pinned_like(slot, name, value.shape, value.dtype)
@@ -305,7 +458,7 @@ def predict_feature_files(model, vocab, paths: Sequence[str], batch_size: int, b
         for step in range(slots):                      # oldest first
             finish((index + step) % slots)
     finally:
-        if workers > 0:                                # leaving early (an exception above): let the copier thread and its loader go
+        if free_ring is not None:                      # leaving early (an exception above): let the copier thread and its loader go
             stopping.set()
             free_ring.put(0)
             while copier.is_alive():

@@ -323,6 +323,10 @@ def test_pipelined_prediction_matches_the_sequential_loop(tmp_path):
             fed = predict_feature_files(model, vocab, paths, batch_size=batch_size, beam_size=want["beam_size"], slots=2,
                                         workers=2, loader_context=context)
             assert fed == sequential, (batch_size, context)
+        # (the default above: workers collate straight into a shared page-locked ring; direct=False: the copier thread)
+        copied = predict_feature_files(model, vocab, paths, batch_size=batch_size, beam_size=want["beam_size"], slots=2, workers=2, direct=False)
+        assert copied == sequential, batch_size
+        assert getattr(model, "_predict_pipeline", {}).get("shared_ring") is not None, "the shared page-locked ring was not used"
         early = predict_feature_files(model, vocab, paths, batch_size=batch_size, beam_size=want["beam_size"], slots=2, early_exit=True)
         assert early == sequential, batch_size
     assert [name for name, _ in sequential] == [os.path.basename(p) for p in paths]

@@ -178,3 +178,47 @@ def test_feature_file_loader_collates_like_the_sequential_loop(tmp_path):
                     assert fields[name] == want[name]
     single = collate_feature_fields([FeatureFileDataset(paths)[0]])
     assert single["region_features"].shape[0] == 1 and single["filename"] == ["img_00.npz"]
+
+
+def test_workers_collate_a_batch_straight_into_a_shared_ring(tmp_path):
+    """The zero-copy hand-off of the prediction loop (data.FeatureBatchDataset): one item = one whole batch, written by the worker
+    into slot b % nslots of shared-memory buffers (page-locked by the parent on the GPU box; plain shared memory here).  What
+    lands in a slot must be exactly the sequential collate -- zero padding of ragged region counts included, over whatever an
+    earlier batch left in the slot -- and a batch that does not fit its slot must come back as an ordinary tensor."""
+    import numpy as np
+    import torch
+    from torch.utils.data import DataLoader
+    from openviic_amd.data import FeatureBatchDataset, _identity, _ring_capacities, batch_from_feature_files
+    g = torch.Generator().manual_seed(3)
+    paths = []
+    for i in range(23):
+        n = int(torch.randint(3, 9, (1,), generator=g))
+        path = str(tmp_path / ("img_%02d.npz" % i))
+        np.savez(path, region_features=torch.randn(n, 16, generator=g).numpy(), region_boxes=torch.rand(n, 4, generator=g).numpy())
+        paths.append(path)
+    caps = _ring_capacities(paths, 4, None, False)
+    assert caps["region_features"] >= 4 * 8 * 16 and caps["region_boxes"] >= 4 * 8 * 4
+    nslots = 3
+    ring = {"region_features": [torch.full((caps["region_features"],), float("nan")).share_memory_() for _ in range(nslots)],
+            "region_boxes": [torch.full((4 * 5 * 4,), float("nan")).share_memory_() for _ in range(nslots)]}     # too small for 6+ regions
+    dataset = FeatureBatchDataset(paths, 4, None, False, ring, nslots)
+    assert len(dataset) == 6
+    for workers in (0, 2):
+        through_ring = fallbacks = 0
+        for b, fields in enumerate(DataLoader(dataset, batch_size=None, shuffle=False, num_workers=workers, collate_fn=_identity,
+                                              prefetch_factor=1 if workers else None)):
+            want = batch_from_feature_files(paths[4 * b:4 * b + 4])
+            assert fields["filename"] == want["filename"]
+            for name in ("region_features", "region_boxes"):
+                value = fields[name]
+                if isinstance(value, (tuple, list)):
+                    tag, slot, shape = value
+                    assert tag == "__ring__" and slot == b % nslots
+                    numel = int(np.prod(shape))
+                    got = ring[name][slot][:numel].view(tuple(shape))
+                    through_ring += 1
+                else:
+                    got = value
+                    fallbacks += 1
+                assert torch.equal(got, want[name]), (workers, b, name)
+        assert through_ring >= 6 and fallbacks >= 1            # the features always fit; some box batches have more than 5 regions
