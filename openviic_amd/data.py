@@ -259,9 +259,8 @@ def predict_feature_files(model, vocab, paths: Sequence[str], batch_size: int, b
 
     ``early_exit=True``: decode with ``ovc_beam_search_early`` -- no step is issued once every beam of the batch has ended (real
     captions end well before ``max_len``); same strings.  That call blocks the launching thread until its batch is one step
-    from done, so batches overlap less; with the host side in worker processes that costs little at large batches -- at the
-    reference's test batch size of 1 it costs more than the steps it saves (4.0 ms per caption against 1.4: the overlap of
-    four searches is worth more than half a search; tools/b1_loop_probe.py).
+    from done, so each slot's search runs on its own host thread (the call is one C function: the GIL is released for all of it)
+    and the slots keep overlapping.
 
     ``slots``: batches in flight, each on its own decode stream.  Default 4: a small batch is a chain of ~730 dependent launches
     of a few workgroups each -- four of them overlap almost freely (B = 1, files -> strings, 8 workers: 430 captions/s with two
@@ -290,10 +289,25 @@ def predict_feature_files(model, vocab, paths: Sequence[str], batch_size: int, b
     pending = [None] * slots                         # (filenames, pinned ids, done event) of the batch in flight on a slot
     results = []
 
+    def search(slot, items, ready, names):
+        with torch.no_grad(), torch.cuda.stream(decode_streams[slot]):
+            decode_streams[slot].wait_event(ready)
+            outs, _ = model.beam_search(items, batch_size=items.batch_size, beam_size=beam_size, out_size=1, early_exit=early_exit)
+            ids_host = pinned_like(slot, "__ids__", outs.shape, outs.dtype)
+            ids_host.copy_(outs, non_blocking=True)
+            done = torch.cuda.Event()
+            done.record(decode_streams[slot])
+        return names, ids_host, done
+
+    searchers = None
+    if early_exit and slots > 1:
+        from concurrent.futures import ThreadPoolExecutor
+        searchers = ThreadPoolExecutor(max_workers=slots, thread_name_prefix="ovc-search")
+
     def finish(slot):
         entry, pending[slot] = pending[slot], None
         if entry is not None:
-            names, ids_host, done = entry
+            names, ids_host, done = entry.result() if searchers else entry
             done.synchronize()
             results.extend(zip(names, captions_from_ids(vocab, ids_host)))
             if ring_of.get(slot) is not None:          # the batch's copy to the device is long done: its ring entry is free again
@@ -440,15 +454,10 @@ def predict_feature_files(model, vocab, paths: Sequence[str], batch_size: int, b
                             items[name] = value
                     ready = torch.cuda.Event()
                     ready.record(copy_stream)
-                with torch.cuda.stream(decode_streams[slot]):
-                    decode_streams[slot].wait_event(ready)
-                    outs, _ = model.beam_search(items, batch_size=items.batch_size, beam_size=beam_size, out_size=1,
-                                                early_exit=early_exit)
-                    ids_host = pinned_like(slot, "__ids__", outs.shape, outs.dtype)
-                    ids_host.copy_(outs, non_blocking=True)
-                    done = torch.cuda.Event()
-                    done.record(decode_streams[slot])
-                pending[slot] = (list(host["filename"]) if "filename" in host else [None] * items.batch_size, ids_host, done)
+                names = list(host["filename"]) if "filename" in host else [None] * items.batch_size
+                # early exit: the search call blocks until its batch is nearly done, so each slot's search runs on its own
+                # thread (the call is ONE C function: the GIL is released for all of it) and the slots overlap as before
+                pending[slot] = searchers.submit(search, slot, items, ready, names) if searchers else search(slot, items, ready, names)
                 ring_of[slot] = entry
                 if trace:
                     now = time.perf_counter()
@@ -458,6 +467,8 @@ def predict_feature_files(model, vocab, paths: Sequence[str], batch_size: int, b
         for step in range(slots):                      # oldest first
             finish((index + step) % slots)
     finally:
+        if searchers:
+            searchers.shutdown(wait=True)
         if free_ring is not None:                      # leaving early (an exception above): let the copier thread and its loader go
             stopping.set()
             free_ring.put(0)
