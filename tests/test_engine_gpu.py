@@ -332,6 +332,38 @@ def test_pipelined_prediction_matches_the_sequential_loop(tmp_path):
     assert [name for name, _ in sequential] == [os.path.basename(p) for p in paths]
 
 
+@pytest.mark.timeout(180)
+@pytest.mark.parametrize("direct", [True, False])
+def test_a_missing_feature_file_surfaces_and_the_loop_recovers(tmp_path, direct):
+    """A worker that cannot read its file: the error must reach the caller (not hang the loop -- the workers, the copier thread and
+    the searches in flight all have to let go), with the shared page-locked ring and with the copier thread, and the next call on
+    good files must work and give the sequential loop's strings."""
+    import json
+    import os
+    from helpers import GOLDEN
+    from openviic_amd.builders import build_model
+    from openviic_amd.checkpoint import load_reference_checkpoint
+    from openviic_amd.config import model_config
+    from openviic_amd.data import predict_feature_files
+    from openviic_amd.vocab import WordVocab
+    want = json.load(open(os.path.join(GOLDEN, "g9_prediction_loop.json")))
+    vocab = WordVocab(want["itos"], max_caption_length=TINY_SHAPE["T"])
+    model = build_model(model_config("standard_transformer", device="cuda", **TINY), vocab).eval()
+    load_reference_checkpoint(model, os.path.join(GOLDEN, "g7_reference_checkpoint_standard_transformer.pth"))
+    g = torch.Generator().manual_seed(9)
+    paths = []
+    for i in range(24):
+        path = str(tmp_path / ("img_%02d.npz" % i))
+        np.savez(path, region_features=torch.randn(TINY_SHAPE["N"], TINY["d_feature"], generator=g).numpy())
+        paths.append(path)
+    good = predict_feature_files(model, vocab, paths, batch_size=2, beam_size=want["beam_size"])
+    broken = paths[:13] + [str(tmp_path / "no_such_image.npz")] + paths[13:]
+    with pytest.raises((FileNotFoundError, OSError, RuntimeError)):
+        predict_feature_files(model, vocab, broken, batch_size=2, beam_size=want["beam_size"], workers=2, direct=direct)
+    again = predict_feature_files(model, vocab, paths, batch_size=2, beam_size=want["beam_size"], workers=2, direct=direct)
+    assert again == good
+
+
 @pytest.mark.parametrize("variant", ["meshed_memory_transformer", "object_relation_transformer", "attention_on_attention"])
 def test_batch_256_properties_other_architectures(variant):
     """BASELINE configs 3 and 4 (and AoA) at the full batch: halves == whole == first 16 alone, exactly."""
